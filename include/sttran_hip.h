@@ -1,0 +1,168 @@
+/* sttran_hip.h -- C ABI of the MI355X-native STTran relation-transformer hot path.
+ *
+ * The reference (rlqja1107/NL-VSGG) has no FFI boundary on this path: the path is the Python
+ * call `pred = model(entry)` (tools/test_STTran.py:84) into `STTran.forward`
+ * (lib/sttran.py:375-411) -> `transformer.forward` (lib/transformer.py:130-187).  This header is
+ * the boundary a drop-in replacement introduces *under* that call; every entry point cites the
+ * reference code it stands in for.  Plain pointers and sizes only -- no torch types.
+ *
+ * Threading: one handle per process/GPU; calls on one handle must be serialised by the caller.
+ * sttran_forward only enqueues work on the supplied stream (no host synchronisation) when the
+ * caller passes `frame_counts`; otherwise it reads `im_idx` back once (the reference itself
+ * synchronises twice per frame, lib/transformer.py:138-140).
+ * Errors: every function returns STTRAN_OK or a negative-free error code; no exceptions cross
+ * the ABI; sttran_last_error() gives the message of the last failure on that handle.
+ */
+#ifndef STTRAN_HIP_H
+#define STTRAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SttranHandle SttranHandle;
+
+enum {
+  STTRAN_OK = 0,
+  STTRAN_ERR_INVALID = 1,  /* bad argument / struct_size / shape                          */
+  STTRAN_ERR_HIP = 2,      /* a HIP runtime call failed                                   */
+  STTRAN_ERR_EMPTY = 3,    /* no pairs: the reference passes `{}` on and crashes later
+                              (tools/test_STTran.py:83-87); here it is an explicit error  */
+  STTRAN_ERR_WEIGHTS = 4,  /* forward before all tensors of the state-dict were loaded    */
+  STTRAN_ERR_ORDER = 5,    /* im_idx not sorted ascending (lib/transformer.py:138 assumes) */
+  STTRAN_ERR_LIMIT = 6     /* a sequence exceeds the attention kernel's key limit          */
+};
+
+enum { STTRAN_MODE_PREDCLS = 0, STTRAN_MODE_SGCLS = 1, STTRAN_MODE_SGDET = 2 };
+enum { STTRAN_DTYPE_F32 = 0, STTRAN_DTYPE_I64 = 1, STTRAN_DTYPE_I32 = 2 };
+
+/* Constructor arguments of `STTran.__init__` (lib/sttran.py:316-318) that shape the compute. */
+typedef struct SttranConfig {
+  uint32_t struct_size;        /* = sizeof(SttranConfig) */
+  int32_t device;              /* HIP device ordinal */
+  int32_t mode;                /* STTRAN_MODE_*; sgdet means sgdet + is_wks (lib/sttran.py:173-184) */
+  int32_t enc_layers;          /* enc_layer_num (1) */
+  int32_t dec_layers;          /* dec_layer_num (3) */
+  int32_t attention_classes;   /* 3  */
+  int32_t spatial_classes;     /* 6  */
+  int32_t contact_classes;     /* 17 */
+  int32_t num_obj_classes;     /* len(obj_classes) = 37 incl. background */
+  int32_t feat_dim;            /* 2048 */
+  int32_t embed_dim;           /* 1936 (lib/sttran.py:358) */
+  int32_t nhead;               /* 8 */
+  int32_t ffn_dim;             /* 2048 */
+} SttranConfig;
+
+/* The `entry` dict read by STTran.forward.  All tensor pointers are DEVICE
+ * pointers to contiguous row-major fp32 / int64 data; counts are host values.
+ * A call may carry several clips back to back (num_clips > 1): frames are then numbered
+ * consecutively over the whole batch and temporal windows never span a clip boundary.  With
+ * num_clips == 1 this is exactly one reference call. */
+typedef struct SttranInputs {
+  uint32_t struct_size;          /* = sizeof(SttranInputs) */
+  int32_t num_clips;             /* >= 1 */
+  int64_t num_boxes;             /* B */
+  int64_t num_pairs;             /* P */
+  int32_t num_frames;            /* T over all clips; 0 = derive as im_idx[-1]+1 (D2H sync) */
+  int32_t im_idx_dtype;          /* STTRAN_DTYPE_F32 (predcls) or STTRAN_DTYPE_I64 (sgdet) */
+  const int32_t* clip_num_frames;/* HOST [num_clips]; may be NULL when num_clips == 1 */
+  const int32_t* frame_counts;   /* HOST [num_frames] pairs per frame, or NULL (derive: sync) */
+  const float* features;         /* [B, feat_dim]            entry['features']       */
+  const int64_t* pair_idx;       /* [P, 2] global box rows   entry['pair_idx']       */
+  const int64_t* labels;         /* [B]                      entry['labels']         */
+  const float* union_feat;       /* [P, feat_dim, 7, 7] NCHW entry['union_feat']     */
+  const float* spatial_masks;    /* [P, 2, 27, 27]           entry['spatial_masks']  */
+  const void* im_idx;            /* [P] frame id of each pair, sorted ascending      */
+  const float* boxes;            /* [B, 5] sgdet only        entry['boxes']          */
+  const float* distribution;     /* [B, num_obj_classes-1] sgdet only                */
+} SttranInputs;
+
+/* Tensors STTran.forward writes into `entry` (lib/sttran.py:404-409, :182).  Caller-allocated
+ * device buffers.  The three *_tap pointers are optional (NULL) stage outputs for parity tests. */
+typedef struct SttranOutputs {
+  uint32_t struct_size;            /* = sizeof(SttranOutputs) */
+  uint32_t reserved;
+  float* attention_distribution;   /* [P, attention_classes]  raw logits          */
+  float* spatial_distribution;     /* [P, spatial_classes]    sigmoid             */
+  float* contacting_distribution;  /* [P, contact_classes]    sigmoid             */
+  float* distribution;             /* [B, num_obj_classes] sgdet only, else NULL  */
+  float* rel_features_tap;         /* [P, embed_dim]  lib/sttran.py:399           */
+  float* local_output_tap;         /* [P, embed_dim]  lib/transformer.py:145      */
+  float* global_output_tap;        /* [P, embed_dim]  lib/transformer.py:187      */
+} SttranOutputs;
+
+/* Per-kernel-class device time, measured with HIP events on the forward's own stream while
+ * profiling is enabled (bench.py's roofline leg). */
+#define STTRAN_PROF_CLASSES 8
+enum {
+  STTRAN_PROF_GEMM = 0,       /* gemm_f32_mfma (all Linear layers, conv2 as implicit GEMM) */
+  STTRAN_PROF_UNION_CONV = 1, /* union_func1 1x1 conv                                      */
+  STTRAN_PROF_MASK_CONV = 2,  /* conv stack stage 1 + pool, im2col                         */
+  STTRAN_PROF_ATTENTION = 3,
+  STTRAN_PROF_LAYERNORM = 4,
+  STTRAN_PROF_INDEX = 5,      /* gather / scatter / embedding / split-K reduce             */
+  STTRAN_PROF_OTHER = 6
+};
+typedef struct SttranProfile {
+  uint32_t struct_size;
+  uint32_t forwards;                       /* forwards accumulated since profile_reset     */
+  double ms[STTRAN_PROF_CLASSES];          /* summed launch durations per class            */
+  double flops[STTRAN_PROF_CLASSES];       /* algorithmic FLOPs (2*M*N*K, unpadded)        */
+  double bytes[STTRAN_PROF_CLASSES];       /* algorithmic bytes (operands + outputs once)  */
+  uint64_t launches[STTRAN_PROF_CLASSES];
+} SttranProfile;
+
+/* `STTran(...)` constructor, lib/sttran.py:316-372 (weights are NOT initialised here). */
+int sttran_create(const SttranConfig* cfg, SttranHandle** out);
+/* `model.load_state_dict(ckpt['state_dict'], strict=False)`, tools/test_STTran.py:51-52.
+ * `key` is the reference state-dict key; data is fp32 (or int64 for
+ * num_batches_tracked, ignored).  `on_device` != 0 means `data` is a device pointer.
+ * Unknown keys are ignored (strict=False) and reported through the return of
+ * sttran_missing_keys. */
+int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const int64_t* shape,
+                       int32_t ndim, int32_t dtype, int32_t on_device);
+/* Derive fused parameters (BatchNorm scale/shift, position-embedding biases, packed heads);
+ * called implicitly by the first forward.  Returns STTRAN_ERR_WEIGHTS if keys are missing. */
+int sttran_finalize_weights(SttranHandle* h);
+/* Writes a '\n'-separated list of still-missing state-dict keys into buf; returns their count. */
+int sttran_missing_keys(SttranHandle* h, char* buf, int64_t buflen);
+/* Pre-size the workspace (otherwise grown on demand by forward; growth synchronises). */
+int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes);
+/* `pred = model(entry)` under torch.no_grad(), tools/test_STTran.py:84 ->
+ * STTran.forward lib/sttran.py:375-411.  `stream` is a hipStream_t (NULL = default stream). */
+int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs* out, void* stream);
+/* Waits for `stream` and reports index errors the kernels met (pair_idx / labels out of range:
+ * torch would raise an IndexError at lib/sttran.py:381-393; the kernels clamp and flag). */
+int sttran_sync_check(SttranHandle* h, void* stream);
+/* `del model` */
+void sttran_destroy(SttranHandle* h);
+const char* sttran_last_error(SttranHandle* h);
+const char* sttran_version(void);
+
+/* profiling (no reference counterpart; SURVEY 5 "Tracing / profiling: none") */
+int sttran_profile_enable(SttranHandle* h, int32_t enable);
+int sttran_profile_reset(SttranHandle* h);
+int sttran_profile_read(SttranHandle* h, SttranProfile* out); /* synchronises the stream */
+
+/* Kernel-level test hooks: each runs ONE kernel class on caller-provided device buffers so the
+ * parity tests can check kernels in isolation (tests/test_kernels_gpu.py). */
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+ residual); tile_cfg 0 = auto, split_k 0 = auto. */
+int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* W, const float* bias,
+                      const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                      int32_t relu, int32_t tile_cfg, int32_t split_k, void* stream);
+/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */
+int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                           int64_t rows, int64_t dim, void* stream);
+/* Multi-head attention core on packed qkv [tokens, 3*dim] over sequences given by
+ * (seq_off, seq_len) device arrays; out [tokens, dim].  nn.MultiheadAttention semantics
+ * (q scaled by 1/sqrt(dim/nhead), softmax over the keys of the same sequence). */
+int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32_t* seq_len,
+                           int32_t num_seq, int32_t max_len, float* out, int64_t tokens,
+                           int32_t dim, int32_t nhead, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STTRAN_HIP_H */

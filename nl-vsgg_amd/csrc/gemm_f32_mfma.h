@@ -1,0 +1,239 @@
+// gemm_f32_mfma.h -- exact-fp32 MFMA GEMM for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )        A rows optionally gathered through rowidx
+//
+// Every dense contraction of the STTran path (nn.Linear: lib/sttran.py:346-348,370-372,
+// lib/transformer.py:9-12,38-42; conv3x3 as implicit GEMM: lib/sttran.py:342) runs through this
+// kernel.  Parity with the fp32 reference is 1e-3, so the matrix pipe is driven with
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate -- bit-identical to an fmaf chain), whose peak
+// is 64 FLOP/clk/SIMD = 157.3 TFLOP/s per MI355X.
+//
+// Structure (one workgroup = WM x WN wavefronts of 64 lanes, block tile BM x BN, BK = 32):
+//   * both operands are K-contiguous rows ("NT" GEMM), staged global -> VGPR -> LDS as whole
+//     128-byte row segments (8 lanes x dwordx4 per row: full cache lines);
+//   * LDS rows are padded to 36 dwords, which makes the ds_read_b128 fragment reads
+//     conflict-free (36*i mod 64 hits 16 distinct 4-dword slots for any 16 rows);
+//   * one ds_read_b128 per lane feeds FOUR MFMAs: lane (r, h) holds k = kb+4h+{0..3}; MFMA j
+//     consumes element j of both fragments, i.e. k = kb+j and kb+4+j -- the k order inside a
+//     group of 8 is permuted identically for A and B, which leaves the dot product unchanged;
+//   * double-buffered LDS, global loads of tile t+1 are issued before the MFMAs of tile t and
+//     written to the other buffer after them: one barrier per K-step;
+//   * blockIdx is remapped so that workgroups sharing a weight panel sit on one XCD (its L2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sttran {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBK = 32;        // K-step
+constexpr int kLdsStride = 36; // dwords per staged row (32 + 4 pad)
+
+struct GemmOperand {
+  const float* ptr;
+  int64_t ld;          // row stride in floats (multiple of 4, 16-byte aligned base)
+  const int* rowidx;   // optional gather: logical row r reads physical row rowidx[r]
+};
+
+// ---- epilogues: called once per output element as epi(row, col, acc) --------------------
+struct EpiLinear {
+  float* C; int64_t ldc;
+  const float* bias;        // [N] or null
+  const float* rowbias;     // [2][rb_ld] extra bias selected by rowslot[row] for col < rb_cols
+  const uint8_t* rowslot;
+  int rb_cols; int rb_ld;
+  const float* scale;       // per-col affine applied after bias (BatchNorm eval), or null
+  const float* shift;
+  const float* res; int64_t ldres; const int* res_rowidx;   // residual add, optional gather
+  int relu;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    if (bias) v += bias[col];
+    if (rowbias && col < rb_cols) v += rowbias[(int)rowslot[row] * rb_ld + col];
+    if (scale) v = v * scale[col] + shift[col];
+    if (relu) v = fmaxf(v, 0.f);
+    if (res) v += res[(int64_t)(res_rowidx ? res_rowidx[row] : row) * ldres + col];
+    C[(int64_t)row * ldc + col] = v;
+  }
+};
+
+// split-K partial slab: slab[z][row][col]
+struct EpiSlab {
+  float* slab; int64_t ld; int64_t zstride;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    slab[(int64_t)blockIdx.z * zstride + (int64_t)row * ld + col] = v;
+  }
+};
+
+// relation heads (lib/sttran.py:404-409): cols [0,na) raw logits, the rest through sigmoid,
+// written to three caller buffers.
+struct EpiHeads {
+  float* att; float* spa; float* con; const float* bias; int na, ns, nc;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    v += bias[col];
+    if (col < na) { att[(int64_t)row * na + col] = v; return; }
+    v = 1.f / (1.f + expf(-v));
+    if (col < na + ns) spa[(int64_t)row * ns + (col - na)] = v;
+    else con[(int64_t)row * nc + (col - na - ns)] = v;
+  }
+};
+
+// conv3x3 as GEMM with M = out channel, N = (pair, hw): ReLU then eval-BatchNorm
+// (lib/sttran.py:342-344: the BN follows the ReLU, so it cannot be folded into the conv),
+// stored channel-major into V[p][c][hw] (the layout `.view(-1, 256*7*7)` flattens, :387).
+struct EpiConvRelBn {
+  float* V; const float* bias; const float* scale; const float* shift; int C; int HW;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    v = fmaxf(v + bias[row], 0.f) * scale[row] + shift[row];
+    int p = col / HW, hw = col - p * HW;
+    V[((int64_t)p * C + row) * HW + hw] = v;
+  }
+};
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct GemmTile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;      // float4 loads per thread per step
+  static constexpr int STAGE = (BM + BN) * kLdsStride;          // floats per LDS stage
+  static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+};
+
+// XCD-aware, bijective remap of a linear block id: ids that are equal mod 8 share an XCD, so
+// give each XCD a contiguous chunk of the logical tile order (guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT)
+gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int kchunk, int tiles_m, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (logical % tiles_m) * BM;     // consecutive logical ids share the weight panel
+  const int n0 = (logical / tiles_m) * BN;
+  const int k_begin = blockIdx.z * kchunk;
+  const int k_end = min(K, k_begin + kchunk);
+  const int nsteps = (k_end - k_begin + kBK - 1) / kBK;
+
+  // ---- per-thread staging slots -------------------------------------------------------
+  const int kq4 = (tid & 7) * 4;
+  const float* pa[AV]; const float* pb[BV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int r = (tid >> 3) + i * (NT >> 3);
+    const int g = m0 + r;
+    pa[i] = (g < M) ? A.ptr + (int64_t)(A.rowidx ? A.rowidx[g] : g) * A.ld + kq4 : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int r = (tid >> 3) + i * (NT >> 3);
+    const int g = n0 + r;
+    pb[i] = (g < N) ? B.ptr + (int64_t)(B.rowidx ? B.rowidx[g] : g) * B.ld + kq4 : nullptr;
+  }
+  f32x4 ra[AV], rb[BV];
+  auto load_tile = [&](int k0) {
+    const bool kok = (k0 + kq4) < k_end;      // K is a multiple of 4: a float4 is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      ra[i] = (pa[i] && kok) ? *reinterpret_cast<const f32x4*>(pa[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      rb[i] = (pb[i] && kok) ? *reinterpret_cast<const f32x4*>(pb[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_tile = [&](float* stage) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int r = (tid >> 3) + i * (NT >> 3);
+      *reinterpret_cast<f32x4*>(stage + r * kLdsStride + kq4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int r = (tid >> 3) + i * (NT >> 3);
+      *reinterpret_cast<f32x4*>(stage + (BM + r) * kLdsStride + kq4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int a_off = (wm * (BM / T::WM) + fr) * kLdsStride + fh * 4;
+  const int b_off = (BM + wn * (BN / T::WN) + fr) * kLdsStride + fh * 4;
+
+  if (nsteps > 0) {
+    load_tile(k_begin);
+    store_tile(smem);
+  }
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    const float* cur = smem + (t & 1) * T::STAGE;
+    if (t + 1 < nsteps) load_tile(k_begin + (t + 1) * kBK);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * kLdsStride + kb * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * kLdsStride + kb * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nsteps) store_tile(smem + ((t + 1) & 1) * T::STAGE);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------------
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
+      const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < M && col < N) epi(row, col, acc[i][j][e]);
+      }
+    }
+  }
+}
+
+// out = epi( sum_z slab[z] ), one thread per element
+template <class Epi>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* slab, int splits, int M, int N, int64_t zstride, Epi epi) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * zstride + i];
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    epi(row, col, s);
+  }
+}
+
+}  // namespace sttran

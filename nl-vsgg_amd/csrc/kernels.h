@@ -1,0 +1,54 @@
+// kernels.h -- host-side launch interface of the HIP kernels (internal to libsttran_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f32_mfma.h"
+
+namespace sttran {
+
+// ---- GEMM ------------------------------------------------------------------------------
+enum { TILE_AUTO = 0, TILE_256x256 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_256x128 = 4, TILE_128x64 = 5,
+       TILE_COUNT = 6 };
+struct GemmPlan { int tile; int splitk; };
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
+size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
+
+hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                       const EpiLinear& epi, GemmPlan plan, float* slab);
+hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                      const EpiHeads& epi, GemmPlan plan, float* slab);
+hipError_t gemm_conv(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                     const EpiConvRelBn& epi, GemmPlan plan, float* slab);
+
+// ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
+// pair_idx/labels (int64) -> int32 gather indices + the two class-embedding column blocks of x
+hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int P, int B,
+                            int num_classes, const float* emb1, const float* emb2, int emb_dim,
+                            int* subj_idx, int* obj_idx, float* x, int ldx, int col_off, int* err_flag);
+// conv7x7/s2/p3 (2->128) + ReLU + BN + maxpool3/s2/p1 : masks [P,2,27,27] -> c2 [P,128,7,7]
+hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w, const float* bias,
+                                  const float* bn_scale, const float* bn_shift, float* c2, int P);
+// im2col for the 3x3/p1 conv on [P,128,7,7] -> [P*49, 1152] rows ordered (ci, ky, kx)
+hipError_t launch_im2col3x3(hipStream_t s, const float* c2, float* cols, int P);
+// union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]   (V already holds the mask-conv branch)
+hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
+                             int P, int K);
+
+// ---- transformer pieces ----------------------------------------------------------------------
+hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
+                            int64_t rows, int dim);
+hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
+                            int num_seq, int max_len, float* out, int dim, int nhead);
+constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel accepts
+hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
+                              int dim);
+
+// ---- ObjectClassifier sgdet+wks (lib/sttran.py:173-184) ---------------------------------------
+// z[b] = [features[b] | distribution[b] @ E0 | ReLU(Linear(BN(center_size(box))))]   -> [B, 2376]
+hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,
+                              const float* E0, const float* pos_scale, const float* pos_shift,
+                              const float* pos_w, const float* pos_b, float* z, int B, int feat_dim,
+                              int ncls, int emb_dim);
+
+}  // namespace sttran

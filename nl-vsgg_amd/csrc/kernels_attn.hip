@@ -1,0 +1,238 @@
+// kernels_attn.hip -- attention core, LayerNorm and row gather of the spatial encoder / temporal
+// decoder (lib/transformer.py:20-30, 49-58; nn.MultiheadAttention semantics).
+#include "kernels.h"
+
+namespace sttran {
+
+// ------------------------------------------------------------------------------------------
+// Fused multi-head attention over ragged sequences.
+//   qkv  [tokens][3*dim]  rows = [q | k | v] projections (bias already added)
+//   out  [tokens][dim]    concat_h softmax(q_h k_h^T / sqrt(hd)) v_h
+// One workgroup = (32-query tile, head, sequence), 4 wavefronts.
+//   phase 1  S = Q K^T     per 32-key tile: K tile staged in LDS (head_dim zero-padded 242->256
+//            so the MFMA K-loop needs no tail), four 16x16 quadrants, one per wave, on
+//            v_mfma_f32_16x16x4_f32 with two interleaved accumulators
+//   softmax  over the LDS score rows, max / sum reduced with wavefront shuffles
+//   phase 2  O = P V       per 32-key tile: V tile staged in the same LDS buffer, P rows read as
+//            the A operand (K-contiguous, ds_read_b128), V read as the B operand with
+//            conflict-free ds_read_b32, 2 x (32x32) output tiles per wave on 32x32x2_f32
+// Sequences are short here (<= 2 x boxes per frame), so K/V are re-staged per query tile.
+// ------------------------------------------------------------------------------------------
+constexpr int kHdPad = 256;           // padded head dim
+constexpr int kQStride = kHdPad + 4;  // 260 dwords: rows land on distinct 4-dword LDS slots
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void stage_head_rows(float* dst, const float* __restrict__ src, int64_t ld,
+                                                int row0, int nrows_valid, int hd, float scale, int tid) {
+  // 32 rows x kQStride; 8 lanes per row, float2 granules (rows are only 8-byte aligned: hd*4 = 968)
+  const int r = tid >> 3, t = tid & 7;
+  const bool rv = r < nrows_valid;
+  const float* s = src + (int64_t)(row0 + r) * ld;
+  float* d = dst + r * kQStride;
+  for (int i = t; i < kQStride / 2; i += 8) {
+    f32x2 v = {0.f, 0.f};
+    if (rv && 2 * i < hd) v = *reinterpret_cast<const f32x2*>(s + 2 * i);
+    v[0] *= scale; v[1] *= scale;
+    *reinterpret_cast<f32x2*>(d + 2 * i) = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
+                 float* __restrict__ out, int dim, int hd, float scale, int skp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
+  const int L = seq_len[s];
+  if (q0 >= L) return;
+  const int base = seq_off[s];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ps = skp + 4;                       // score row stride
+  float* Qs = smem;                             // [32][260]
+  float* KVs = Qs + 32 * kQStride;              // [32][260]
+  float* Ps = KVs + 32 * kQStride;              // [32][skp+4]
+  float* rinv = Ps + 32 * ps;                   // [32]
+  const int64_t ld = 3 * (int64_t)dim;
+  const float* qp = qkv + (int64_t)base * ld + h * hd;
+  const int nkt = (L + 31) / 32;
+
+  stage_head_rows(Qs, qp, ld, q0, min(32, L - q0), hd, scale, tid);
+
+  // ---- phase 1: scores ------------------------------------------------------------------
+  const int qi = wave >> 1, kj = wave & 1, l15 = lane & 15, g = lane >> 4;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();                            // previous tile's reads of KVs are done
+    stage_head_rows(KVs, qp + dim, ld, kt * 32, min(32, L - kt * 32), hd, 1.f, tid);
+    __syncthreads();
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const float* ar = Qs + (qi * 16 + l15) * kQStride + 4 * g;
+    const float* br = KVs + (kj * 16 + l15) * kQStride + 4 * g;
+#pragma unroll 4
+    for (int kb = 0; kb < kHdPad / 16; ++kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + kb * 16);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(br + kb * 16);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1, 0, 0, 0);
+    }
+    // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kt * 32 + kj * 16 + l15] = c0[e] + c1[e];
+  }
+  __syncthreads();
+
+  // ---- softmax over keys [0, L) of each of the 32 rows; 8 rows per wave --------------------
+  for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+    float* pr = Ps + r * ps;
+    float m = -INFINITY;
+    for (int c = lane; c < L; c += 64) m = fmaxf(m, pr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.f;
+    for (int c = lane; c < nkt * 32; c += 64) {
+      const float e = (c < L) ? expf(pr[c] - m) : 0.f;
+      pr[c] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) rinv[r] = 1.f / sum;
+  }
+
+  // ---- phase 2: O = P V -------------------------------------------------------------------
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+  const int d0 = wave * 64;                     // this wave's two 32-column output tiles
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_head_rows(KVs, qp + 2 * dim, ld, kt * 32, min(32, L - kt * 32), hd, 1.f, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + fr * ps + kt * 32 + kb * 8 + 4 * fh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* vr = KVs + (kb * 8 + 4 * fh + e) * kQStride + d0 + fr;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[32], o1, 0, 0, 0);
+      }
+    }
+  }
+  float* op = out + (int64_t)(base + q0) * dim + h * hd;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int q = (e & 3) + 8 * (e >> 2) + 4 * fh;
+    if (q0 + q < L) {
+      const float ri = rinv[q];
+      const int c0 = d0 + fr, c1 = d0 + 32 + fr;
+      if (c0 < hd) op[(int64_t)q * dim + c0] = o0[e] * ri;
+      if (c1 < hd) op[(int64_t)q * dim + c1] = o1[e] * ri;
+    }
+  }
+}
+
+hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
+                            int max_len, float* out, int dim, int nhead) {
+  if (num_seq <= 0 || max_len <= 0) return hipSuccess;
+  const int hd = dim / nhead;
+  if (hd > kHdPad - 2 || (hd & 1) || max_len > kAttnMaxKeys) return hipErrorInvalidValue;
+  const int skp = (max_len + 31) / 32 * 32;
+  const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
+  static int attr_max = 0;
+  if (lds > attr_max) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_max = lds;
+  }
+  dim3 grid((max_len + 31) / 32, nhead, num_seq);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, dim, hd,
+                     1.0f / sqrtf((float)hd), skp);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (biased variance, eps 1e-5): one wavefront per row, the row held in
+// registers between the mean, variance and normalise passes; reductions by wavefront shuffles.
+// ------------------------------------------------------------------------------------------
+constexpr int kLnMaxV = 16;   // float4 per lane -> dim <= 4096
+
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                 float* __restrict__ y, int64_t rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n4 = dim >> 2;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+  f32x4 v[kLnMaxV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = (j < n4) ? xr[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; ++i) {
+    const int j = lane + 64 * i;
+    if (j < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / (float)dim + 1e-5f);
+  f32x4* yr = reinterpret_cast<f32x4*>(y + row * dim);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; ++i) {
+    const int j = lane + 64 * i;
+    if (j < n4) {
+      const f32x4 g = g4[j], b = b4[j];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      yr[j] = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
+                            int64_t rows, int dim) {
+  if (rows <= 0) return hipSuccess;
+  if ((dim & 3) || dim > kLnMaxV * 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y,
+                     rows, dim);
+  return hipGetLastError();
+}
+
+// dst[r, :] = src[idx[r], :]   (window build lib/transformer.py:153, 'latter' scatter :181-185)
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                   int64_t rows, int n4) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * n4;
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * n4;
+  for (int j = threadIdx.x; j < n4; j += 256) d[j] = s[j];
+}
+
+hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
+                              int dim) {
+  if (rows <= 0) return hipSuccess;
+  if (dim & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, idx, dst, rows, dim >> 2);
+  return hipGetLastError();
+}
+
+}  // namespace sttran

@@ -1,0 +1,767 @@
+// sttran_api.hip -- C ABI (include/sttran_hip.h) and host orchestration of STTran.forward
+// (lib/sttran.py:375-411 -> lib/transformer.py:130-187 with the empty-frame handling of
+// lib/transformer_wk.py:144-195).  Host work per call: O(P) integer index maps; everything else is
+// enqueued on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sttran_hip.h"
+#include "kernels.h"
+
+using namespace sttran;
+
+namespace {
+
+struct Tensor {
+  float* d = nullptr;
+  std::vector<int64_t> shape;
+  size_t n = 0;
+  bool required = false, loaded = false;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+    need = (need + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) bytes = need;
+    return e;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfEvent { hipEvent_t a, b; int cls; };
+
+// worst case of build_layout(): 2P (encoder off/len) + 4P (window off/len) + 2P (dec_src) + P (out_src)
+// + P/2 (slots) int32 words
+constexpr int64_t kIdxIntsPerPair = 12;
+
+struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
+
+}  // namespace
+
+struct SttranHandle {
+  SttranConfig cfg{};
+  std::string err;
+  std::map<std::string, Tensor> w;
+  bool finalized = false;
+  // derived parameters
+  DevBuf derived;               // one arena for all derived tensors
+  float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
+  float *heads_w = nullptr, *heads_b = nullptr;
+  float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
+  std::vector<DecLayer> dec;
+  // workspace
+  int64_t capP = 0, capB = 0;
+  DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, cols, slab, idx, zbuf, hobj, ebuf;
+  int* err_flag = nullptr;
+  // index-map staging (pinned) + cache of the last layout
+  static constexpr int kStages = 4;
+  int32_t* stage[kStages] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_cap[kStages] = {0, 0, 0, 0};
+  hipEvent_t stage_ev[kStages] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_next = 0;
+  std::vector<int32_t> cached_counts, cached_clips;
+  int64_t cached_P = -1;
+  // layout of the current index buffer
+  struct Layout {
+    int n_enc_seq = 0, max_enc = 0, n_dec_seq = 0, max_dec = 0;
+    int64_t n_dec_tok = 0;
+    size_t o_enc_off = 0, o_enc_len = 0, o_dec_off = 0, o_dec_len = 0, o_dec_src = 0, o_out_src = 0, o_slot = 0;
+    size_t total_ints = 0;
+  } lay;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfEvent> prof_ev;
+  SttranProfile prof{};
+  hipStream_t prof_stream = nullptr;
+  int32_t* im_host = nullptr;   // pinned scratch for the im_idx read-back
+  size_t im_host_cap = 0;
+};
+
+namespace {
+
+int fail(SttranHandle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+#define HIPCK(expr)                                                                            \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(h, STTRAN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+void add(SttranHandle* h, const std::string& k, std::vector<int64_t> shape, bool required) {
+  Tensor t;
+  t.shape = std::move(shape);
+  t.n = 1;
+  for (int64_t d : t.shape) t.n *= (size_t)d;
+  t.required = required;
+  h->w[k] = t;
+}
+
+void add_linear(SttranHandle* h, const std::string& p, int64_t out, int64_t in, bool req) {
+  add(h, p + ".weight", {out, in}, req);
+  add(h, p + ".bias", {out}, req);
+}
+void add_bn(SttranHandle* h, const std::string& p, int64_t n, bool req) {
+  for (const char* s : {".weight", ".bias", ".running_mean", ".running_var"}) add(h, p + s, {n}, req);
+}
+void add_mha(SttranHandle* h, const std::string& p, int64_t d) {
+  add(h, p + ".in_proj_weight", {3 * d, d}, true);
+  add(h, p + ".in_proj_bias", {3 * d}, true);
+  add_linear(h, p + ".out_proj", d, d, true);
+}
+
+// state-dict of lib/sttran.py:316-372 + lib/transformer.py:116-127
+void declare_weights(SttranHandle* h) {
+  const SttranConfig& c = h->cfg;
+  const int64_t D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
+  const bool oc = c.mode != STTRAN_MODE_PREDCLS;
+  add(h, "object_classifier.obj_embed.weight", {NC - 1, 200}, oc);
+  add_bn(h, "object_classifier.pos_embed.0", 4, oc);
+  add_linear(h, "object_classifier.pos_embed.1", 128, 4, oc);
+  add_linear(h, "object_classifier.decoder_lin.0", 1024, FD + 200 + 128, oc);
+  add_bn(h, "object_classifier.decoder_lin.1", 1024, oc);
+  add_linear(h, "object_classifier.decoder_lin.3", NC, 1024, oc);
+  add(h, "union_func1.weight", {256, FD, 1, 1}, true);
+  add(h, "union_func1.bias", {256}, true);
+  add(h, "conv.0.weight", {128, 2, 7, 7}, true);
+  add(h, "conv.0.bias", {128}, true);
+  add_bn(h, "conv.2", 128, true);
+  add(h, "conv.4.weight", {256, 128, 3, 3}, true);
+  add(h, "conv.4.bias", {256}, true);
+  add_bn(h, "conv.6", 256, true);
+  add_linear(h, "subj_fc", 512, FD, true);
+  add_linear(h, "obj_fc", 512, FD, true);
+  add_linear(h, "vr_fc", 512, 256 * 49, true);
+  add(h, "obj_embed.weight", {NC, 200}, true);
+  add(h, "obj_embed2.weight", {NC, 200}, true);
+  for (int i = 0; i < c.enc_layers; ++i) {
+    const std::string p = "glocal_transformer.local_attention.layers." + std::to_string(i);
+    add_mha(h, p + ".self_attn", D);
+    add_linear(h, p + ".linear1", F, D, true);
+    add_linear(h, p + ".linear2", D, F, true);
+    add(h, p + ".norm1.weight", {D}, true); add(h, p + ".norm1.bias", {D}, true);
+    add(h, p + ".norm2.weight", {D}, true); add(h, p + ".norm2.bias", {D}, true);
+  }
+  for (int i = 0; i < c.dec_layers; ++i) {
+    const std::string p = "glocal_transformer.global_attention.layers." + std::to_string(i);
+    add_mha(h, p + ".multihead2", D);
+    add_linear(h, p + ".linear1", F, D, true);
+    add_linear(h, p + ".linear2", D, F, true);
+    add(h, p + ".norm3.weight", {D}, true); add(h, p + ".norm3.bias", {D}, true);
+  }
+  add(h, "glocal_transformer.position_embedding.weight", {2, D}, true);
+  add_linear(h, "a_rel_compress", c.attention_classes, D, true);
+  add_linear(h, "s_rel_compress", c.spatial_classes, D, true);
+  add_linear(h, "c_rel_compress", c.contact_classes, D, true);
+}
+
+const float* W(SttranHandle* h, const std::string& k) { return h->w[k].d; }
+
+struct ProfScope {
+  SttranHandle* h; hipStream_t s; bool on;
+  ProfEvent ev{};
+  ProfScope(SttranHandle* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_), on(h_->prof_on) {
+    if (!on) return;
+    ev.cls = cls;
+    hipEventCreate(&ev.a);
+    hipEventCreate(&ev.b);
+    hipEventRecord(ev.a, s);
+    h->prof.flops[cls] += flops;
+    h->prof.bytes[cls] += bytes;
+    h->prof.launches[cls] += 1;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(ev.b, s);
+    h->prof_ev.push_back(ev);
+  }
+};
+
+double gemm_flops(int64_t M, int64_t N, int64_t K) { return 2.0 * M * N * K; }
+double gemm_bytes(int64_t M, int64_t N, int64_t K) { return 4.0 * (M * K + N * K + M * N); }
+
+// C = act(A W^T + ...) through the planner; slab workspace grown on demand
+int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, int M, int N, int K, EpiLinear epi,
+               int force_tile = 0, int force_split = 0) {
+  if (M <= 0) return STTRAN_OK;
+  GemmPlan plan = plan_gemm(M, N, K, force_tile, force_split);
+  size_t sf = gemm_slab_floats(plan, M, N);
+  if (sf * 4 > h->slab.bytes) {
+    HIPCK(hipStreamSynchronize(s));
+    HIPCK(h->slab.ensure(sf * 4));
+  }
+  GemmOperand B{Wt, (int64_t)K, nullptr};
+  ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
+  HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>()));
+  return STTRAN_OK;
+}
+
+EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu = 0) {
+  EpiLinear e{};
+  e.C = C; e.ldc = ldc; e.bias = bias; e.relu = relu;
+  return e;
+}
+
+int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
+  if (P <= h->capP && B <= h->capB) return STTRAN_OK;
+  HIPCK(hipDeviceSynchronize());
+  const int64_t cp = std::max(P, h->capP), cb = std::max(B, h->capB);
+  const int64_t D = h->cfg.embed_dim, F = h->cfg.ffn_dim, tok = 2 * cp;
+  HIPCK(h->x0.ensure((size_t)cp * D * 4));
+  HIPCK(h->ebuf.ensure((size_t)cp * D * 4));
+  HIPCK(h->qkv.ensure((size_t)tok * 3 * D * 4));
+  HIPCK(h->att.ensure((size_t)tok * D * 4));
+  HIPCK(h->ybuf.ensure((size_t)tok * D * 4));
+  HIPCK(h->hbuf.ensure((size_t)tok * D * 4));
+  HIPCK(h->f1.ensure((size_t)tok * F * 4));
+  HIPCK(h->gbuf.ensure((size_t)tok * D * 4));
+  HIPCK(h->uni.ensure((size_t)(cp + tok) * D * 4));
+  HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
+  HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
+  HIPCK(h->cols.ensure((size_t)cp * 49 * 1152 * 4));
+  HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + (size_t)cp * 2 * 4 + 4096));
+  if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
+    HIPCK(h->zbuf.ensure((size_t)cb * (h->cfg.feat_dim + 328) * 4));
+    HIPCK(h->hobj.ensure((size_t)cb * 1024 * 4));
+  }
+  h->capP = cp;
+  h->capB = cb;
+  return STTRAN_OK;
+}
+
+// Build the index maps of one call on the host (O(P) integers).
+//   enc sequences : non-empty frames (lib/transformer_wk.py:144-150)
+//   dec sequences : 2-frame windows inside each clip, both-empty windows dropped (:175-185)
+//   dec_src/slot  : window token -> encoder row / position-embedding row (lib/transformer.py:153-159)
+//   out_src       : pair -> row of the unified [encoder rows | decoder rows] buffer, mode 'latter'
+//                   (lib/transformer.py:179-185); clips with one frame keep the encoder row
+//                   (lib/transformer_wk.py:187-188)
+void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P,
+                  std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+  const int T = (int)counts.size();
+  std::vector<int64_t> off(T + 1, 0);
+  for (int t = 0; t < T; ++t) off[t + 1] = off[t] + counts[t];
+  std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P);
+  std::vector<uint8_t> slot;
+  L = SttranHandle::Layout();
+  for (int t = 0; t < T; ++t)
+    if (counts[t] > 0) { enc_off.push_back((int32_t)off[t]); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
+  for (int64_t p = 0; p < P; ++p) out_src[p] = (int32_t)p;
+  int fs = 0;
+  for (size_t c = 0; c < clips.size(); ++c) {
+    const int fe = fs + clips[c];
+    for (int j = fs; j + 1 < fe; ++j) {
+      const int n0 = counts[j], n1 = counts[j + 1];
+      if (n0 + n1 == 0) continue;
+      const int32_t doff = (int32_t)dec_src.size();
+      dec_off.push_back(doff);
+      dec_len.push_back(n0 + n1);
+      L.max_dec = std::max(L.max_dec, n0 + n1);
+      for (int i = 0; i < n0 + n1; ++i) { dec_src.push_back((int32_t)(off[j] + i)); slot.push_back(i < n0 ? 0 : 1); }
+      if (j == fs) for (int i = 0; i < n0; ++i) out_src[off[j] + i] = (int32_t)(P + doff + i);
+      for (int i = 0; i < n1; ++i) out_src[off[j + 1] + i] = (int32_t)(P + doff + n0 + i);
+    }
+    fs = fe;
+  }
+  L.n_enc_seq = (int)enc_off.size();
+  L.n_dec_seq = (int)dec_off.size();
+  L.n_dec_tok = (int64_t)dec_src.size();
+  buf.clear();
+  auto put = [&](const std::vector<int32_t>& v) { size_t o = buf.size(); buf.insert(buf.end(), v.begin(), v.end()); return o; };
+  L.o_enc_off = put(enc_off); L.o_enc_len = put(enc_len);
+  L.o_dec_off = put(dec_off); L.o_dec_len = put(dec_len);
+  L.o_dec_src = put(dec_src); L.o_out_src = put(out_src);
+  L.o_slot = buf.size();
+  buf.resize(buf.size() + (slot.size() + 3) / 4, 0);
+  if (!slot.empty()) memcpy(buf.data() + L.o_slot, slot.data(), slot.size());
+  L.total_ints = buf.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sttran_version(void) { return "sttran-hip 0.1.0 (gfx950, fp32 MFMA)"; }
+
+const char* sttran_last_error(SttranHandle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int sttran_create(const SttranConfig* cfg, SttranHandle** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(SttranConfig)) return STTRAN_ERR_INVALID;
+  if (cfg->embed_dim % 4 || cfg->nhead <= 0 || cfg->embed_dim % cfg->nhead || cfg->feat_dim % 32 ||
+      cfg->ffn_dim % 4 || cfg->enc_layers < 0 || cfg->dec_layers < 0 || cfg->num_obj_classes < 2 ||
+      cfg->num_obj_classes > 64 || cfg->embed_dim != 1536 + 400 ||
+      cfg->attention_classes + cfg->spatial_classes + cfg->contact_classes > 64)
+    return STTRAN_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+    return STTRAN_ERR_HIP;
+  if (hipSetDevice(cfg->device) != hipSuccess) return STTRAN_ERR_HIP;
+  SttranHandle* h = new SttranHandle();
+  h->cfg = *cfg;
+  declare_weights(h);
+  if (hipMalloc(&h->err_flag, 64) != hipSuccess || hipMemset(h->err_flag, 0, 64) != hipSuccess) {
+    delete h;
+    return STTRAN_ERR_HIP;
+  }
+  *out = h;
+  return STTRAN_OK;
+}
+
+void sttran_destroy(SttranHandle* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  hipDeviceSynchronize();
+  for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
+  for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
+                    &h->c2, &h->cols, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
+    b->release();
+  for (int i = 0; i < SttranHandle::kStages; ++i) {
+    if (h->stage[i]) hipHostFree(h->stage[i]);
+    if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+  }
+  if (h->im_host) hipHostFree(h->im_host);
+  for (auto& e : h->prof_ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  if (h->err_flag) hipFree(h->err_flag);
+  delete h;
+}
+
+int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const int64_t* shape, int32_t ndim,
+                       int32_t dtype, int32_t on_device) {
+  if (!h || !key || !data || (ndim > 0 && !shape) || ndim < 0) return fail(h, STTRAN_ERR_INVALID, "load_tensor: bad argument");
+  auto it = h->w.find(key);
+  if (it == h->w.end()) return STTRAN_OK;   // strict=False: unknown keys (num_batches_tracked, ...) are ignored
+  Tensor& t = it->second;
+  if (dtype != STTRAN_DTYPE_F32) return fail(h, STTRAN_ERR_INVALID, std::string(key) + ": expected float32");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  bool same = (size_t)ndim == t.shape.size();
+  for (int i = 0; same && i < ndim; ++i) same = shape[i] == t.shape[i];
+  if (!same || n != t.n) return fail(h, STTRAN_ERR_INVALID, std::string(key) + ": shape mismatch");
+  HIPCK(hipSetDevice(h->cfg.device));
+  if (!t.d) HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), std::max<size_t>(t.n * 4, 16)));
+  HIPCK(hipMemcpy(t.d, data, t.n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  t.loaded = true;
+  h->finalized = false;
+  return STTRAN_OK;
+}
+
+int sttran_missing_keys(SttranHandle* h, char* buf, int64_t buflen) {
+  if (!h) return -1;
+  int n = 0;
+  std::string s;
+  for (auto& kv : h->w)
+    if (kv.second.required && !kv.second.loaded) { ++n; s += kv.first; s += '\n'; }
+  if (buf && buflen > 0) {
+    strncpy(buf, s.c_str(), (size_t)buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return n;
+}
+
+int sttran_finalize_weights(SttranHandle* h) {
+  if (!h) return STTRAN_ERR_INVALID;
+  if (h->finalized) return STTRAN_OK;
+  for (auto& kv : h->w)
+    if (kv.second.required && !kv.second.loaded) return fail(h, STTRAN_ERR_WEIGHTS, "missing weight: " + kv.first);
+  HIPCK(hipSetDevice(h->cfg.device));
+  const SttranConfig& c = h->cfg;
+  const int64_t D = c.embed_dim;
+  const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
+  const bool oc = c.mode != STTRAN_MODE_PREDCLS;
+  // arena layout (floats)
+  size_t total = 2 * 128 + 2 * 256 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  HIPCK(h->derived.ensure(total * 4));
+  float* p = h->derived.as<float>();
+  auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
+  h->bn1_scale = take(128); h->bn1_shift = take(128);
+  h->bn2_scale = take(256); h->bn2_shift = take(256);
+  h->heads_w = take((size_t)nh * D); h->heads_b = take(64);
+  h->dec.resize(c.dec_layers);
+  for (int i = 0; i < c.dec_layers; ++i) h->dec[i].posbias = take(4 * D);
+  h->oc_pos_scale = take(4); h->oc_pos_shift = take(4);
+  h->oc_bn_scale = take(1024); h->oc_bn_shift = take(1024);
+
+  // eval-mode BatchNorm -> per-channel scale/shift: y = x*s + t, s = g/sqrt(var+eps), t = b - mean*s
+  auto bn = [&](const std::string& pre, int n, float* ds, float* dt) -> int {
+    std::vector<float> g(n), b(n), m(n), v(n), s(n), t(n);
+    HIPCK(hipMemcpy(g.data(), W(h, pre + ".weight"), n * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(b.data(), W(h, pre + ".bias"), n * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(m.data(), W(h, pre + ".running_mean"), n * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(v.data(), W(h, pre + ".running_var"), n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+      const double sd = (double)g[i] / std::sqrt((double)v[i] + 1e-5);
+      s[i] = (float)sd;
+      t[i] = (float)((double)b[i] - (double)m[i] * sd);
+    }
+    HIPCK(hipMemcpy(ds, s.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(dt, t.data(), n * 4, hipMemcpyHostToDevice));
+    return STTRAN_OK;
+  };
+  int rc;
+  if ((rc = bn("conv.2", 128, h->bn1_scale, h->bn1_shift))) return rc;
+  if ((rc = bn("conv.6", 256, h->bn2_scale, h->bn2_shift))) return rc;
+  if (oc) {
+    if ((rc = bn("object_classifier.pos_embed.0", 4, h->oc_pos_scale, h->oc_pos_shift))) return rc;
+    if ((rc = bn("object_classifier.decoder_lin.1", 1024, h->oc_bn_scale, h->oc_bn_shift))) return rc;
+  }
+  // packed relation heads [a | s | c] (lib/sttran.py:370-372)
+  {
+    size_t ro = 0;
+    const std::pair<const char*, int> hs[3] = {{"a_rel_compress", c.attention_classes},
+                                               {"s_rel_compress", c.spatial_classes},
+                                               {"c_rel_compress", c.contact_classes}};
+    for (auto& kv : hs) {
+      HIPCK(hipMemcpy(h->heads_w + ro * D, W(h, std::string(kv.first) + ".weight"), (size_t)kv.second * D * 4,
+                      hipMemcpyDeviceToDevice));
+      HIPCK(hipMemcpy(h->heads_b + ro, W(h, std::string(kv.first) + ".bias"), (size_t)kv.second * 4,
+                      hipMemcpyDeviceToDevice));
+      ro += kv.second;
+    }
+  }
+  // position embedding folded into a per-slot bias of the q/k projections:
+  //   (g + pos) Wqk^T + b = g Wqk^T + (pos Wqk^T) + b      (lib/transformer.py:51, pos is one of 2 rows)
+  for (int i = 0; i < c.dec_layers; ++i) {
+    const std::string pre = "glocal_transformer.global_attention.layers." + std::to_string(i) + ".multihead2";
+    GemmOperand A{W(h, "glocal_transformer.position_embedding.weight"), D, nullptr};
+    EpiLinear e = epi_plain(h->dec[i].posbias, 2 * D, nullptr);
+    if ((rc = run_linear(h, nullptr, A, W(h, pre + ".in_proj_weight"), 2, (int)(2 * D), (int)D, e))) return rc;
+  }
+  HIPCK(hipDeviceSynchronize());
+  h->finalized = true;
+  return STTRAN_OK;
+}
+
+int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes) {
+  if (!h || max_pairs < 0 || max_boxes < 0) return STTRAN_ERR_INVALID;
+  HIPCK(hipSetDevice(h->cfg.device));
+  return ensure_workspace(h, max_pairs, max_boxes);
+}
+
+int sttran_profile_enable(SttranHandle* h, int32_t enable) {
+  if (!h) return STTRAN_ERR_INVALID;
+  h->prof_on = enable != 0;
+  return STTRAN_OK;
+}
+
+int sttran_profile_reset(SttranHandle* h) {
+  if (!h) return STTRAN_ERR_INVALID;
+  for (auto& e : h->prof_ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  h->prof_ev.clear();
+  memset(&h->prof, 0, sizeof(h->prof));
+  return STTRAN_OK;
+}
+
+int sttran_profile_read(SttranHandle* h, SttranProfile* out) {
+  if (!h || !out || out->struct_size != sizeof(SttranProfile)) return STTRAN_ERR_INVALID;
+  HIPCK(hipStreamSynchronize(h->prof_stream));
+  for (auto& e : h->prof_ev) {
+    float ms = 0.f;
+    HIPCK(hipEventElapsedTime(&ms, e.a, e.b));
+    h->prof.ms[e.cls] += ms;
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  h->prof_ev.clear();
+  h->prof.struct_size = sizeof(SttranProfile);
+  *out = h->prof;
+  return STTRAN_OK;
+}
+
+int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs* out, void* stream_) {
+  if (!h) return STTRAN_ERR_INVALID;
+  if (!in || !out || in->struct_size != sizeof(SttranInputs) || out->struct_size != sizeof(SttranOutputs))
+    return fail(h, STTRAN_ERR_INVALID, "forward: bad struct_size");
+  const SttranConfig& c = h->cfg;
+  const int64_t P = in->num_pairs, B = in->num_boxes;
+  if (P <= 0 || B <= 0) return fail(h, STTRAN_ERR_EMPTY, "forward: entry has no pairs");
+  if (P > (1 << 28) / 49 || B > (1 << 30)) return fail(h, STTRAN_ERR_LIMIT, "forward: too many pairs");
+  if (!in->features || !in->pair_idx || !in->labels || !in->union_feat || !in->spatial_masks ||
+      !out->attention_distribution || !out->spatial_distribution || !out->contacting_distribution)
+    return fail(h, STTRAN_ERR_INVALID, "forward: null tensor pointer");
+  const bool oc = c.mode != STTRAN_MODE_PREDCLS;
+  if (oc && (!in->boxes || !in->distribution || !out->distribution))
+    return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs boxes, distribution and an output distribution");
+  if (in->num_clips < 1 || (in->num_clips > 1 && !in->clip_num_frames))
+    return fail(h, STTRAN_ERR_INVALID, "forward: bad clip description");
+  HIPCK(hipSetDevice(c.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+  h->prof_stream = s;
+  int rc;
+  if (!h->finalized && (rc = sttran_finalize_weights(h))) return rc;
+  if ((rc = ensure_workspace(h, P, B))) return rc;
+
+  // ---- per-frame pair counts ---------------------------------------------------------------
+  std::vector<int32_t> counts;
+  if (in->frame_counts && in->num_frames > 0) {
+    counts.assign(in->frame_counts, in->frame_counts + in->num_frames);
+  } else {
+    if (!in->im_idx) return fail(h, STTRAN_ERR_INVALID, "forward: neither frame_counts nor im_idx given");
+    const size_t esz = in->im_idx_dtype == STTRAN_DTYPE_I64 ? 8 : 4;
+    if (h->im_host_cap < (size_t)P * 8) {
+      if (h->im_host) HIPCK(hipHostFree(h->im_host));
+      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->im_host), (size_t)P * 8));
+      h->im_host_cap = (size_t)P * 8;
+    }
+    HIPCK(hipMemcpyAsync(h->im_host, in->im_idx, (size_t)P * esz, hipMemcpyDeviceToHost, s));
+    HIPCK(hipStreamSynchronize(s));
+    int64_t prev = -1;
+    for (int64_t p = 0; p < P; ++p) {
+      int64_t f;
+      if (in->im_idx_dtype == STTRAN_DTYPE_I64) f = reinterpret_cast<const int64_t*>(h->im_host)[p];
+      else if (in->im_idx_dtype == STTRAN_DTYPE_I32) f = h->im_host[p];
+      else f = (int64_t)reinterpret_cast<const float*>(h->im_host)[p];
+      if (f < prev || f < 0) return fail(h, STTRAN_ERR_ORDER, "forward: im_idx must be non-negative and sorted ascending");
+      if ((size_t)f >= counts.size()) counts.resize((size_t)f + 1, 0);
+      counts[(size_t)f]++;
+      prev = f;
+    }
+    if (in->num_frames > (int)counts.size()) counts.resize(in->num_frames, 0);
+  }
+  int64_t tot = 0;
+  for (int32_t v : counts) { if (v < 0) return fail(h, STTRAN_ERR_INVALID, "forward: negative frame count"); tot += v; }
+  if (tot != P) return fail(h, STTRAN_ERR_INVALID, "forward: frame_counts do not sum to num_pairs");
+  std::vector<int32_t> clips;
+  if (in->num_clips == 1) clips.push_back((int32_t)counts.size());
+  else {
+    clips.assign(in->clip_num_frames, in->clip_num_frames + in->num_clips);
+    int64_t tf = 0;
+    for (int32_t v : clips) { if (v < 0) return fail(h, STTRAN_ERR_INVALID, "forward: negative clip length"); tf += v; }
+    if (tf != (int64_t)counts.size()) return fail(h, STTRAN_ERR_INVALID, "forward: clip_num_frames do not sum to num_frames");
+  }
+
+  // ---- index maps (cached while the layout repeats) -----------------------------------------
+  if (!(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips)) {
+    std::vector<int32_t> buf;
+    build_layout(counts, clips, P, buf, h->lay);
+    if (h->lay.max_enc > kAttnMaxKeys || h->lay.max_dec > kAttnMaxKeys)
+      return fail(h, STTRAN_ERR_LIMIT, "forward: a frame/window exceeds the attention key limit");
+    const int k = h->stage_next;
+    h->stage_next = (k + 1) % SttranHandle::kStages;
+    if (h->stage_ev[k]) HIPCK(hipEventSynchronize(h->stage_ev[k]));
+    else HIPCK(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+    if (h->stage_cap[k] < buf.size() * 4) {
+      if (h->stage[k]) HIPCK(hipHostFree(h->stage[k]));
+      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->stage[k]), buf.size() * 4 + 4096));
+      h->stage_cap[k] = buf.size() * 4 + 4096;
+    }
+    memcpy(h->stage[k], buf.data(), buf.size() * 4);
+    if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
+    HIPCK(hipMemcpyAsync(h->idx.p, h->stage[k], buf.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCK(hipEventRecord(h->stage_ev[k], s));
+    h->cached_P = P; h->cached_counts = counts; h->cached_clips = clips;
+  }
+  const SttranHandle::Layout& L = h->lay;
+  const int32_t* ib = h->idx.as<int32_t>();
+  const int* enc_off = ib + L.o_enc_off; const int* enc_len = ib + L.o_enc_len;
+  const int* dec_off = ib + L.o_dec_off; const int* dec_len = ib + L.o_dec_len;
+  const int* dec_src = ib + L.o_dec_src; const int* out_src = ib + L.o_out_src;
+  const uint8_t* slot = reinterpret_cast<const uint8_t*>(ib + L.o_slot);
+  int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
+  int* obj_idx = subj_idx + h->capP;
+
+  const int D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
+  float* X0 = h->x0.as<float>();
+  float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
+  float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>(); float* G = h->gbuf.as<float>();
+  float* UNI = h->uni.as<float>(); float* V = h->vbuf.as<float>(); float* C2 = h->c2.as<float>();
+  float* COLS = h->cols.as<float>(); float* E = h->ebuf.as<float>();
+
+  // ---- ObjectClassifier, sgdet + is_wks (lib/sttran.py:173-184) ------------------------------
+  if (oc) {
+    float* Z = h->zbuf.as<float>(); float* HO = h->hobj.as<float>();
+    const int zd = FD + 200 + 128;
+    {
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * B * (2.0 * zd));
+      HIPCK(launch_objcls_prep(s, in->features, in->distribution, in->boxes, W(h, "object_classifier.obj_embed.weight"),
+                               h->oc_pos_scale, h->oc_pos_shift, W(h, "object_classifier.pos_embed.1.weight"),
+                               W(h, "object_classifier.pos_embed.1.bias"), Z, (int)B, FD, NC - 1, 200));
+    }
+    EpiLinear e1 = epi_plain(HO, 1024, W(h, "object_classifier.decoder_lin.0.bias"), 1);
+    e1.scale = h->oc_bn_scale; e1.shift = h->oc_bn_shift;     // Linear -> BN -> ReLU
+    if ((rc = run_linear(h, s, GemmOperand{Z, zd, nullptr}, W(h, "object_classifier.decoder_lin.0.weight"), (int)B, 1024, zd, e1))) return rc;
+    EpiLinear e2 = epi_plain(out->distribution, NC, W(h, "object_classifier.decoder_lin.3.bias"));
+    if ((rc = run_linear(h, s, GemmOperand{HO, 1024, nullptr}, W(h, "object_classifier.decoder_lin.3.weight"), (int)B, NC, 1024, e2))) return rc;
+  }
+
+  // ---- pair fusion (lib/sttran.py:381-399) -> X0 [P, 1936] -----------------------------------
+  {
+    ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2);
+    HIPCK(launch_pair_prep(s, in->pair_idx, in->labels, (int)P, (int)B, NC, W(h, "obj_embed.weight"),
+                           W(h, "obj_embed2.weight"), 200, subj_idx, obj_idx, X0, D, 1536, h->err_flag));
+  }
+  if ((rc = run_linear(h, s, GemmOperand{in->features, FD, subj_idx}, W(h, "subj_fc.weight"), (int)P, 512, FD,
+                       epi_plain(X0, D, W(h, "subj_fc.bias"))))) return rc;
+  if ((rc = run_linear(h, s, GemmOperand{in->features, FD, obj_idx}, W(h, "obj_fc.weight"), (int)P, 512, FD,
+                       epi_plain(X0 + 512, D, W(h, "obj_fc.bias"))))) return rc;
+  {
+    ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 6272));
+    HIPCK(launch_mask_conv1_pool(s, in->spatial_masks, W(h, "conv.0.weight"), W(h, "conv.0.bias"), h->bn1_scale,
+                                 h->bn1_shift, C2, (int)P));
+  }
+  {
+    ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 0, 4.0 * P * (6272 + 49.0 * 1152));
+    HIPCK(launch_im2col3x3(s, C2, COLS, (int)P));
+  }
+  {
+    // conv3x3 as GEMM: M = 256 out channels, N = P*49 positions, K = 1152
+    const int M = 256, N = (int)(P * 49), K = 1152;
+    GemmPlan plan = plan_gemm(M, N, K, 0, 1);
+    EpiConvRelBn e{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
+    HIPCK(gemm_conv(s, GemmOperand{W(h, "conv.4.weight"), K, nullptr}, GemmOperand{COLS, K, nullptr}, M, N, K, e,
+                    plan, nullptr));
+  }
+  {
+    ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
+    HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD));
+  }
+  if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
+                       epi_plain(X0 + 1024, D, W(h, "vr_fc.bias"))))) return rc;
+  if (out->rel_features_tap)
+    HIPCK(hipMemcpyAsync(out->rel_features_tap, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+
+  // ---- spatial encoder, one sequence per non-empty frame (lib/transformer.py:20-30,144) --------
+  const float* xin = X0;
+  for (int i = 0; i < c.enc_layers; ++i) {
+    const std::string p = "glocal_transformer.local_attention.layers." + std::to_string(i);
+    float* xout = (i == c.enc_layers - 1) ? UNI : E;
+    if ((rc = run_linear(h, s, GemmOperand{xin, D, nullptr}, W(h, p + ".self_attn.in_proj_weight"), (int)P, 3 * D, D,
+                         epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
+    {
+      ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * P * L.max_enc * D, 4.0 * P * 4 * D);
+      HIPCK(launch_attention(s, QKV, enc_off, enc_len, L.n_enc_seq, L.max_enc, ATT, D, c.nhead));
+    }
+    EpiLinear eo = epi_plain(Y, D, W(h, p + ".self_attn.out_proj.bias"));
+    eo.res = xin; eo.ldres = D;
+    if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".self_attn.out_proj.weight"), (int)P, D, D, eo))) return rc;
+    {
+      ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * P * D);
+      HIPCK(launch_layernorm(s, Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, P, D));
+    }
+    if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), (int)P, F, D,
+                         epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
+    EpiLinear e2 = epi_plain(Y, D, W(h, p + ".linear2.bias"));
+    e2.res = H; e2.ldres = D;
+    if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), (int)P, D, F, e2))) return rc;
+    {
+      ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * P * D);
+      HIPCK(launch_layernorm(s, Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, P, D));
+    }
+    xin = xout;
+  }
+  if (c.enc_layers == 0) HIPCK(hipMemcpyAsync(UNI, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+  if (out->local_output_tap)
+    HIPCK(hipMemcpyAsync(out->local_output_tap, UNI, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+
+  // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
+  const int NT = (int)L.n_dec_tok;
+  float* UDEC = UNI + (size_t)P * D;
+  if (NT > 0 && c.dec_layers > 0) {
+    {
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D);
+      HIPCK(launch_gather_rows(s, UNI, dec_src, G, NT, D));
+    }
+    for (int i = 0; i < c.dec_layers; ++i) {
+      const std::string p = "glocal_transformer.global_attention.layers." + std::to_string(i);
+      float* gout = (i == c.dec_layers - 1) ? UDEC : G;
+      EpiLinear eq = epi_plain(QKV, 3 * D, W(h, p + ".multihead2.in_proj_bias"));
+      eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
+      if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, W(h, p + ".multihead2.in_proj_weight"), NT, 3 * D, D, eq))) return rc;
+      {
+        ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * NT * L.max_dec * D, 4.0 * NT * 4 * D);
+        HIPCK(launch_attention(s, QKV, dec_off, dec_len, L.n_dec_seq, L.max_dec, ATT, D, c.nhead));
+      }
+      EpiLinear eo = epi_plain(Y, D, W(h, p + ".multihead2.out_proj.bias"));
+      eo.res = G; eo.ldres = D;
+      if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".multihead2.out_proj.weight"), NT, D, D, eo))) return rc;
+      {
+        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * NT * D);
+        HIPCK(launch_layernorm(s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, NT, D));
+      }
+      if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), NT, F, D,
+                           epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
+      EpiLinear e2 = epi_plain(gout, D, W(h, p + ".linear2.bias"));
+      e2.res = H; e2.ldres = D;
+      if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), NT, D, F, e2))) return rc;
+    }
+  } else if (NT > 0) {
+    HIPCK(launch_gather_rows(s, UNI, dec_src, UDEC, NT, D));   // dec_layers == 0: windows pass through
+  }
+  if (out->global_output_tap) HIPCK(launch_gather_rows(s, UNI, out_src, out->global_output_tap, P, D));
+
+  // ---- relation heads on the 'latter' rows (lib/sttran.py:404-409, lib/transformer.py:179-185) --
+  {
+    const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
+    EpiHeads eh{out->attention_distribution, out->spatial_distribution, out->contacting_distribution, h->heads_b,
+                c.attention_classes, c.spatial_classes, c.contact_classes};
+    GemmPlan plan = plan_gemm(P, nh, D, TILE_64x64, 1);
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D));
+    HIPCK(gemm_heads(s, GemmOperand{UNI, D, out_src}, GemmOperand{h->heads_w, D, nullptr}, (int)P, nh, D, eh, plan,
+                     nullptr));
+  }
+  if (h->prof_on) h->prof.forwards += 1;
+  return STTRAN_OK;
+}
+
+int sttran_sync_check(SttranHandle* h, void* stream) {
+  if (!h) return STTRAN_ERR_INVALID;
+  HIPCK(hipSetDevice(h->cfg.device));
+  HIPCK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  int flag = 0;
+  HIPCK(hipMemcpy(&flag, h->err_flag, 4, hipMemcpyDeviceToHost));
+  if (flag) {
+    HIPCK(hipMemset(h->err_flag, 0, 4));
+    return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx or labels out of range (values were clamped)");
+  }
+  return STTRAN_OK;
+}
+
+// ---- kernel-level test hooks -------------------------------------------------------------------
+int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, const float* bias,
+                      const float* residual, float* C, int64_t M, int64_t N, int64_t K, int32_t relu,
+                      int32_t tile_cfg, int32_t split_k, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3)) return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmPlan plan = plan_gemm(M, N, K, tile_cfg, split_k);
+  float* slab = nullptr;
+  size_t sf = gemm_slab_floats(plan, M, N);
+  if (sf && hipMalloc(reinterpret_cast<void**>(&slab), sf * 4) != hipSuccess) return STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  hipError_t err = gemm_linear(s, GemmOperand{A, K, a_rowidx}, GemmOperand{Wt, K, nullptr}, (int)M, (int)N, (int)K,
+                               e, plan, slab);
+  if (slab) { hipStreamSynchronize(s); hipFree(slab); }
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                           int64_t dim, void* stream) {
+  if (!x || !gamma || !beta || !y) return STTRAN_ERR_INVALID;
+  return launch_layernorm(reinterpret_cast<hipStream_t>(stream), x, gamma, beta, y, rows, (int)dim) == hipSuccess
+             ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
+                           int32_t max_len, float* out, int64_t tokens, int32_t dim, int32_t nhead, void* stream) {
+  (void)tokens;
+  if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
+  return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, num_seq, max_len, out, dim,
+                          nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+}  // extern "C"

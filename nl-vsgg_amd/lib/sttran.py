@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference `lib/sttran.py::STTran` on top of the HIP library.
+
+Same constructor signature (`lib/sttran.py:316-318`), same call protocol as
+`tools/test_STTran.py:38-52,84`:
+
+    model = STTran(mode=..., attention_class_num=3, spatial_class_num=6, contact_class_num=17,
+                   obj_classes=classes, enc_layer_num=1, dec_layer_num=3, transformer_mode='wk',
+                   is_wks=True, feat_dim=2048).to(device)
+    model.eval(); model.load_state_dict(ckpt['state_dict'], strict=False)
+    pred = model(entry)            # mutates and returns `entry`
+
+`entry` is the dict of CUDA tensors the reference detector produces; the keys
+written are the ones `lib/evaluation_recall.py:397-465` reads.  PyTorch is used only for device
+memory and the current stream; all compute happens in `csrc/` through the C ABI.  There is no
+CPU path: without the HIP library (or without a GPU) construction of the handle raises.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+
+_IncompatibleKeys = collections.namedtuple("_IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
+def _host_i32(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+
+class STTran:
+    """Inference-only STTran (PredCls, and SGDet with `is_wks=True`)."""
+
+    def __init__(self, mode="sgdet", attention_class_num=None, spatial_class_num=None, contact_class_num=None,
+                 obj_classes=None, enc_layer_num=None, dec_layer_num=None, transformer_mode=None, is_wks=True,
+                 feat_dim=2048, motifs_path=None, conf=None):
+        assert mode in ("sgdet", "sgcls", "predcls")          # lib/sttran.py:329
+        if mode == "sgcls" or (mode == "sgdet" and not is_wks):
+            raise NotImplementedError(
+                "only predcls and sgdet+is_wks are on the hot path (the other ObjectClassifier branches "
+                "need the detector's ROIAlign/NMS ops, lib/sttran.py:185-283)")
+        self.conf = conf
+        self.mode = mode
+        self.is_wks = is_wks
+        self.obj_classes = obj_classes
+        self.attention_class_num = attention_class_num
+        self.spatial_class_num = spatial_class_num
+        self.contact_class_num = contact_class_num
+        self.transformer_mode = transformer_mode
+        self.motifs_path = motifs_path
+        self.enc_layer_num = int(enc_layer_num)
+        self.dec_layer_num = int(dec_layer_num)
+        self.feat_dim = int(feat_dim)
+        self.training = False
+        self.taps = False               # parity tests: also return stage tensors
+        self.check_indices = False      # synchronise and validate pair_idx/labels after each call
+        self._device = None
+        self._handle = None
+        self._sd = {}
+        self._lib = nat.load()          # raises if the HIP extension is missing
+
+    # ---- nn.Module-like surface ------------------------------------------------------------
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("STTran runs on an MI355X only (no CPU path)")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._handle is not None and idx != self._device:
+            self._destroy()
+        self._device = idx
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("inference only (SURVEY.md 2, row 18: training is out of scope)")
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def load_state_dict(self, state_dict, strict=False):
+        """`model.load_state_dict(ckpt['state_dict'], strict=False)` (tools/test_STTran.py:51-52)."""
+        self._sd = dict(state_dict)
+        if self._handle is not None:
+            self._upload()
+        missing, unexpected = self._key_report()
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing}, unexpected {unexpected}")
+        return _IncompatibleKeys(missing, unexpected)
+
+    # ---- handle management -------------------------------------------------------------------
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the STTran hot path has no CPU fallback")
+        if self._device is None:
+            self._device = torch.cuda.current_device()
+        cfg = nat.SttranConfig(
+            struct_size=C.sizeof(nat.SttranConfig), device=self._device, mode=nat.MODE[self.mode],
+            enc_layers=self.enc_layer_num, dec_layers=self.dec_layer_num,
+            attention_classes=int(self.attention_class_num), spatial_classes=int(self.spatial_class_num),
+            contact_classes=int(self.contact_class_num), num_obj_classes=len(self.obj_classes),
+            feat_dim=self.feat_dim, embed_dim=1936, nhead=8, ffn_dim=2048)
+        h = C.c_void_p()
+        rc = self._lib.sttran_create(C.byref(cfg), C.byref(h))
+        if rc != nat.STTRAN_OK:
+            raise nat.SttranError(rc, "sttran_create failed")
+        self._handle = h
+        if self._sd:
+            self._upload()
+
+    def _upload(self):
+        lib, h = self._lib, self._handle
+        for k, v in self._sd.items():
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            if not t.dtype.is_floating_point:
+                continue                                   # num_batches_tracked
+            t = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            on_dev = 1 if t.is_cuda else 0
+            if t.is_cuda and t.device.index != self._device:
+                t, on_dev = t.cpu(), 0
+            nat.check(lib, h, lib.sttran_load_tensor(h, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(),
+                                                     nat.DTYPE_F32, on_dev))
+        if self._key_report()[0] == []:
+            nat.check(lib, h, lib.sttran_finalize_weights(h))
+
+    def _key_report(self):
+        if self._handle is None:
+            return [], []
+        buf = C.create_string_buffer(1 << 16)
+        n = self._lib.sttran_missing_keys(self._handle, buf, len(buf))
+        missing = [s for s in buf.value.decode().split("\n") if s] if n else []
+        return missing, []
+
+    def _destroy(self):
+        if self._handle is not None:
+            self._lib.sttran_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    # ---- profiling hooks used by bench.py ----------------------------------------------------------
+    def profile(self, enable=True, reset=True):
+        self._ensure_handle()
+        if reset:
+            nat.check(self._lib, self._handle, self._lib.sttran_profile_reset(self._handle))
+        nat.check(self._lib, self._handle, self._lib.sttran_profile_enable(self._handle, 1 if enable else 0))
+
+    def profile_read(self):
+        p = nat.SttranProfile(struct_size=C.sizeof(nat.SttranProfile))
+        nat.check(self._lib, self._handle, self._lib.sttran_profile_read(self._handle, C.byref(p)))
+        return {nat.PROF_NAMES[i]: {"ms": p.ms[i], "flops": p.flops[i], "bytes": p.bytes[i],
+                                    "launches": int(p.launches[i])} for i in range(7)} | {"forwards": int(p.forwards)}
+
+    def reserve(self, max_pairs, max_boxes):
+        self._ensure_handle()
+        nat.check(self._lib, self._handle, self._lib.sttran_reserve(self._handle, int(max_pairs), int(max_boxes)))
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _dev(self, t, dtype):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        dev = torch.device("cuda", self._device)
+        if t.device != dev or t.dtype != dtype:
+            t = t.to(device=dev, dtype=dtype)
+        return t.contiguous()
+
+    def __call__(self, entry):
+        return self.forward(entry)
+
+    def forward(self, entry):
+        """`STTran.forward` (lib/sttran.py:375-411).  `entry` may carry two optional host-side hints
+        that avoid the read-back of `im_idx`: `frame_counts` (pairs per frame) and, for a batch of
+        clips packed by `pack_clips`, `clip_num_frames`."""
+        self._ensure_handle()
+        lib, h = self._lib, self._handle
+        f32, i64 = torch.float32, torch.int64
+        feats = self._dev(entry["features"], f32)
+        pair = self._dev(entry["pair_idx"], i64)
+        labels = self._dev(entry["labels"], i64)
+        union = self._dev(entry["union_feat"], f32)
+        masks = self._dev(entry["spatial_masks"], f32)
+        P, B = int(pair.shape[0]), int(feats.shape[0])
+        if P == 0:
+            raise nat.SttranError(3, "entry has no pairs")
+        if union.shape[0] != P or masks.shape[0] != P or labels.shape[0] != B or feats.shape[1] != self.feat_dim:
+            raise ValueError("entry tensors disagree on the number of pairs / boxes")
+        im = entry["im_idx"]
+        im_dtype = nat.DTYPE_I64 if (isinstance(im, torch.Tensor) and not im.dtype.is_floating_point) else nat.DTYPE_F32
+        im = self._dev(im, i64 if im_dtype == nat.DTYPE_I64 else f32)
+        counts = _host_i32(entry.get("frame_counts"))
+        clips = _host_i32(entry.get("clip_num_frames"))
+        dev = feats.device
+        att = torch.empty((P, self.attention_class_num), dtype=f32, device=dev)
+        spa = torch.empty((P, self.spatial_class_num), dtype=f32, device=dev)
+        con = torch.empty((P, self.contact_class_num), dtype=f32, device=dev)
+        inp = nat.SttranInputs(struct_size=C.sizeof(nat.SttranInputs),
+                               num_clips=1 if clips is None else len(clips), num_boxes=B, num_pairs=P,
+                               num_frames=0 if counts is None else len(counts), im_idx_dtype=im_dtype)
+        if counts is not None:
+            inp.frame_counts = counts.ctypes.data_as(C.POINTER(C.c_int32))
+        elif "num_frames" in entry:
+            inp.num_frames = int(entry["num_frames"])
+        if clips is not None:
+            inp.clip_num_frames = clips.ctypes.data_as(C.POINTER(C.c_int32))
+        inp.features, inp.pair_idx, inp.labels = feats.data_ptr(), pair.data_ptr(), labels.data_ptr()
+        inp.union_feat, inp.spatial_masks, inp.im_idx = union.data_ptr(), masks.data_ptr(), im.data_ptr()
+        out = nat.SttranOutputs(struct_size=C.sizeof(nat.SttranOutputs))
+        out.attention_distribution, out.spatial_distribution = att.data_ptr(), spa.data_ptr()
+        out.contacting_distribution = con.data_ptr()
+        keep = [feats, pair, labels, union, masks, im]
+        if self.mode != "predcls":
+            boxes = self._dev(entry["boxes"], f32)
+            dist_in = self._dev(entry["distribution"], f32)
+            dist_out = torch.empty((B, len(self.obj_classes)), dtype=f32, device=dev)
+            inp.boxes, inp.distribution, out.distribution = boxes.data_ptr(), dist_in.data_ptr(), dist_out.data_ptr()
+            keep += [boxes, dist_in]
+        taps = {}
+        if self.taps:
+            for k in ("rel_features", "local_output", "global_output"):
+                taps[k] = torch.empty((P, 1936), dtype=f32, device=dev)
+                setattr(out, k + "_tap", taps[k].data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
+        if self.check_indices:
+            nat.check(lib, h, lib.sttran_sync_check(h, C.c_void_p(stream)))
+        # ---- the keys the reference writes (lib/sttran.py:91,182-184,404-409) ----
+        entry["pred_labels"] = entry["labels"]
+        if self.mode != "predcls":
+            entry["distribution"] = dist_out
+            entry["pred_scores"] = entry["scores"]
+        entry["attention_distribution"] = att
+        entry["spatial_distribution"] = spa
+        entry["contacting_distribution"] = con
+        for k, v in taps.items():
+            entry["_tap_" + k] = v
+        return entry
+
+
+def pack_clips(entries):
+    """Concatenate several clips into one `entry` the HIP path processes in a single pass.
+
+    Frames are renumbered consecutively, box rows of `pair_idx` are offset, and the host-side
+    `clip_num_frames` / `frame_counts` hints are attached so temporal windows stop at clip borders
+    (no reference counterpart: the reference batch is one clip, dataloader/wk_action_genome.py:622-627).
+    Use `unpack_predictions` to split the outputs again."""
+    cat = {}
+    box_off = frame_off = 0
+    pair, im, counts, clips = [], [], [], []
+    for e in entries:
+        fc = _host_i32(e.get("frame_counts"))
+        if fc is None:
+            fr = e["im_idx"].detach().cpu().numpy().astype(np.int64)
+            fc = np.bincount(fr, minlength=int(e.get("num_frames", fr[-1] + 1))).astype(np.int32)
+        pair.append(e["pair_idx"] + box_off)
+        im.append(e["im_idx"] + frame_off)
+        counts.append(fc)
+        clips.append(len(fc))
+        box_off += int(e["features"].shape[0])
+        frame_off += len(fc)
+    for k in ("features", "labels", "union_feat", "spatial_masks", "boxes", "scores", "distribution"):
+        if all(k in e for e in entries):
+            cat[k] = torch.cat([e[k] for e in entries], dim=0)
+    cat["pair_idx"] = torch.cat(pair, dim=0)
+    cat["im_idx"] = torch.cat(im, dim=0)
+    cat["frame_counts"] = np.concatenate(counts)
+    cat["clip_num_frames"] = np.asarray(clips, dtype=np.int32)
+    cat["num_frames"] = int(frame_off)
+    cat["_pairs_per_clip"] = [int(e["pair_idx"].shape[0]) for e in entries]
+    cat["_boxes_per_clip"] = [int(e["features"].shape[0]) for e in entries]
+    return cat
+
+
+def unpack_predictions(packed):
+    """Split the *_distribution outputs of a packed entry back into one dict per clip."""
+    outs = []
+    p0 = b0 = 0
+    for np_, nb in zip(packed["_pairs_per_clip"], packed["_boxes_per_clip"]):
+        d = {k: packed[k][p0:p0 + np_] for k in ("attention_distribution", "spatial_distribution",
+                                                 "contacting_distribution")}
+        if "distribution" in packed and packed["distribution"].shape[0] == sum(packed["_boxes_per_clip"]):
+            d["distribution"] = packed["distribution"][b0:b0 + nb]
+        outs.append(d)
+        p0 += np_
+        b0 += nb
+    return outs

@@ -1,0 +1,157 @@
+"""Kernel-level parity through the C ABI test hooks (sttran_debug_*), one kernel class at a time.
+The comparison values are float64 torch/numpy restatements of the single op (a fp32 reference of a
+floating-point kernel, as the brief asks), tolerance 1e-4 relative to the output scale."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd import _native
+    return _native.load()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _gemm(lib, A, W, bias=None, res=None, rowidx=None, relu=0, tile=0, split=0):
+    M = A.shape[0] if rowidx is None else rowidx.shape[0]
+    N, K = W.shape
+    Cc = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32)
+    rc = lib.sttran_debug_gemm(_p(A), _p(rowidx), _p(W), _p(bias), _p(res), _p(Cc), M, N, K, relu, tile, split, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return Cc
+
+
+def _ref(A, W, bias=None, res=None, rowidx=None, relu=0):
+    a = A.double() if rowidx is None else A.double()[rowidx.long()]
+    r = a @ W.double().T
+    if bias is not None:
+        r = r + bias.double()
+    if relu:
+        r = r.clamp_min(0)
+    if res is not None:
+        r = r + res.double()
+    return r
+
+
+SHAPES = [(1, 1, 4), (2, 3872, 1936), (33, 70, 100), (176, 512, 2048), (330, 5808, 1936), (257, 129, 36),
+          (64, 64, 32), (300, 26, 1936), (130, 1936, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_gemm_tiles(lib, M, N, K, tile):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    out = _gemm(lib, A, W, bias=b, tile=tile, split=1)
+    ref = _ref(A, W, b)
+    tol = 1e-5 * (K ** 0.5) * 4 + 1e-5
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
+
+
+@pytest.mark.parametrize("split", [2, 4, 8])
+def test_gemm_split_k(lib, split):
+    g = torch.Generator(device="cuda").manual_seed(split)
+    M, N, K = 176, 512, 12544
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.01
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    out = _gemm(lib, A, W, bias=b, res=res, relu=1, tile=3, split=split)
+    ref = _ref(A, W, b, res, relu=1)
+    assert (out.double() - ref).abs().max().item() < 2e-4
+
+
+def test_gemm_gather_rows(lib):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.randn(50, 2048, device="cuda", generator=g)
+    W = torch.randn(512, 2048, device="cuda", generator=g) * 0.02
+    idx = torch.randint(0, 50, (176,), device="cuda", generator=g, dtype=torch.int32)
+    out = _gemm(lib, A, W, rowidx=idx)
+    ref = _ref(A, W, rowidx=idx)
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+def test_gemm_auto_plan_matches(lib):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = torch.randn(2240, 1936, device="cuda", generator=g)
+    W = torch.randn(2048, 1936, device="cuda", generator=g) * 0.02
+    out = _gemm(lib, A, W)
+    assert (out.double() - _ref(A, W)).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 1936), (7, 1936), (330, 1936), (5, 2376), (3, 4096), (9, 8)])
+def test_layernorm(lib, rows, dim):
+    g = torch.Generator(device="cuda").manual_seed(rows + dim)
+    x = torch.randn(rows, dim, device="cuda", generator=g) * 3 + 1
+    gm = torch.rand(dim, device="cuda", generator=g) + 0.5
+    bt = torch.rand(dim, device="cuda", generator=g) - 0.5
+    y = torch.empty_like(x)
+    assert lib.sttran_debug_layernorm(_p(x), _p(gm), _p(bt), _p(y), rows, dim, None) == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (dim,), gm.double(), bt.double(), 1e-5)
+    assert (y.double() - ref).abs().max().item() < 1e-5
+
+
+def _attn_ref(qkv, offs, lens, dim, nhead):
+    hd = dim // nhead
+    out = torch.zeros(qkv.shape[0], dim, dtype=torch.float64, device=qkv.device)
+    q, k, v = qkv.double().split(dim, dim=1)
+    for o, l in zip(offs, lens):
+        if l == 0:
+            continue
+        qs = q[o:o + l].view(l, nhead, hd).transpose(0, 1) / hd ** 0.5
+        ks = k[o:o + l].view(l, nhead, hd).transpose(0, 1)
+        vs = v[o:o + l].view(l, nhead, hd).transpose(0, 1)
+        a = torch.softmax(qs @ ks.transpose(1, 2), dim=-1)
+        out[o:o + l] = (a @ vs).transpose(0, 1).reshape(l, dim)
+    return out
+
+
+@pytest.mark.parametrize("lens", [[1], [22] * 15, [70, 3, 35, 64, 33], [5, 0, 9], [129, 31], [480]])
+def test_attention(lib, lens):
+    dim, nhead = 1936, 8
+    g = torch.Generator(device="cuda").manual_seed(sum(lens))
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    tokens = int(sum(lens))
+    qkv = torch.randn(tokens, 3 * dim, device="cuda", generator=g)
+    qkv[:, :dim] *= 2.0          # sharpen the softmax a little
+    out = torch.full((tokens, dim), float("nan"), device="cuda")
+    so = torch.from_numpy(offs).cuda()
+    sl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_attention(_p(qkv), _p(so), _p(sl), len(lens), max(lens), _p(out), tokens, dim, nhead,
+                                      None) == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(qkv, offs.tolist(), lens, dim, nhead)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+def test_attention_spiked_scores(lib):
+    """one key dominates one query by a large margin: the max-subtraction must hold (guide rule 26)."""
+    dim, nhead, L = 1936, 8, 40
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(L, 3 * dim, device="cuda", generator=g)
+    qkv[3, :dim] *= 40.0
+    qkv[17, dim:2 * dim] = qkv[3, :dim] / 4
+    out = torch.empty(L, dim, device="cuda")
+    so = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sl = torch.full((1,), L, dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_attention(_p(qkv), _p(so), _p(sl), 1, L, _p(out), L, dim, nhead, None) == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(qkv, [0], [L], dim, nhead)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 1e-4

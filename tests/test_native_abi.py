@@ -1,0 +1,59 @@
+"""CPU-only checks of the C-ABI boundary: the library is built, loads without a GPU, and exports
+exactly the entry points include/sttran_hip.h declares, with struct sizes the binding agrees on."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as ge
+    from nl_vsgg_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        ge.build()
+    return _native
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "sttran_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sttran_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(native):
+    lib = native.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sttran_hip.h but not exported"
+    assert sorted(s[0] for s in native.SYMBOLS) == names
+
+
+def test_version_and_null_handle(native):
+    lib = native.load()
+    assert b"gfx950" in lib.sttran_version()
+    assert lib.sttran_last_error(None) == b"null handle"
+    assert lib.sttran_finalize_weights(None) == 1
+
+
+def test_struct_sizes(native):
+    # the library rejects any struct whose struct_size differs from its own sizeof
+    assert C.sizeof(native.SttranConfig) == 13 * 4
+    assert C.sizeof(native.SttranInputs) == 8 + 16 + 8 + 16 + 8 * 8
+    assert C.sizeof(native.SttranOutputs) == 8 + 7 * 8
+    assert C.sizeof(native.SttranProfile) == 8 + 4 * 8 * 8
+    lib = native.load()
+    cfg = native.SttranConfig(struct_size=4)
+    h = C.c_void_p()
+    assert lib.sttran_create(C.byref(cfg), C.byref(h)) == 1      # STTRAN_ERR_INVALID, no GPU touched
+
+
+def test_missing_library_fails_loudly(native, monkeypatch):
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libsttran_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        native.load()
