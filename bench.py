@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the STTran PredCls hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path (`STTran.forward`) over one batch of synthetic clips resident
+in HBM.  Workload (default, BASELINE.json configs[1]): clips of 16 frames x 12 boxes x 2048-d
+region features (P = 176 pairs per clip), `--clips-per-step` clips per pass.  `--workload 64x36`
+selects configs[3]'s clip shape.  With N > 1 every rank runs its own clips (whole-clip sharding,
+weak scaling) and the per-step predictions are all-gathered over RCCL inside the timed region.
+
+One JSON line is printed by rank 0; it carries the roofline of the dominant kernel (the fp32 MFMA
+GEMM: algorithmic 2*M*N*K FLOPs / HIP-event time, measured in a second, instrumented run of the
+same K steps) and a CPU baseline (the numpy oracle on this host's cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+from nl_vsgg_amd.lib.sttran import STTran, pack_clips  # noqa: E402
+
+CLASSES = ["__background__"] + [f"c{i}" for i in range(36)]
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def device_clip(T, N, gen, device):
+    """One synthetic clip of T frames x N boxes (1 person + N-1 objects per frame) built on the
+    device with the distributions of SURVEY.md 8(d)."""
+    B, P = T * N, T * (N - 1)
+    fr = torch.arange(T, device=device).repeat_interleave(N - 1)
+    obj = torch.arange(1, N, device=device).repeat(T)
+    labels = torch.randint(2, 37, (B,), device=device, generator=gen)
+    labels[::N] = 1
+    return {
+        "features": torch.randn(B, 2048, device=device, generator=gen),
+        "union_feat": torch.randn(P, 2048, 7, 7, device=device, generator=gen),
+        "spatial_masks": torch.rand(P, 2, 27, 27, device=device, generator=gen) - 0.5,
+        "labels": labels,
+        "pair_idx": torch.stack([fr * N, fr * N + obj], dim=1),
+        "im_idx": fr.float(),
+        "frame_counts": np.full(T, N - 1, dtype=np.int32),
+        "num_frames": T,
+    }
+
+
+def cpu_baseline(T, N, sd, budget_s=20.0):
+    """The numpy oracle (a port of the reference's CPU path, validated against it by the golden
+    tests) timed on this host: one clip per run, as many runs as fit the budget."""
+    from oracle import sttran_oracle as orc
+    entry = syn.uniform_clip(11, T, N)
+    t0 = time.perf_counter()
+    orc.sttran_forward(entry, sd)                      # warm-up (BLAS threads, page faults)
+    first = time.perf_counter() - t0
+    runs = []
+    while sum(runs) + first < budget_s and len(runs) < 5:
+        t0 = time.perf_counter()
+        orc.sttran_forward(entry, sd)
+        runs.append(time.perf_counter() - t0)
+    med = float(np.median(runs)) if runs else first
+    return {"value": T / med, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{max(len(runs), 1)} forward(s) of one {T}x{N} clip, numpy/BLAS fp32 oracle, "
+                      f"median {med:.3f} s/clip"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="16x12", choices=["16x12", "64x36"])
+    ap.add_argument("--clips-per-step", type=int, default=0, help="0 = default for the workload")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
+
+    T, N = (16, 12) if args.workload == "16x12" else (64, 36)
+    cps = args.clips_per_step or (8 if args.workload == "16x12" else 1)
+    sd = syn.make_sttran_state_dict(7)
+    model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
+                   obj_classes=CLASSES, enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True,
+                   feat_dim=2048).to(device)
+    model.eval()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    batch = pack_clips([device_clip(T, N, gen, device) for _ in range(cps)])
+    P = int(batch["pair_idx"].shape[0])
+    model.reserve(P, int(batch["features"].shape[0]))
+    gathered = torch.empty((world * P, 26), device=device) if world > 1 else None
+
+    def step():
+        pred = model(batch)
+        if world > 1:     # per-clip predictions of every rank, one fixed-size RCCL all-gather
+            mine = torch.cat([pred["attention_distribution"], pred["spatial_distribution"],
+                              pred["contacting_distribution"]], dim=1)
+            dist.all_gather_into_tensor(gathered, mine)
+        return pred
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(pred["attention_distribution"]).all()
+
+    frames_per_step = world * cps * T
+    result = {
+        "metric": "frames/sec (PredCls inference)",
+        "value": frames_per_step * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {T} frames x {N} boxes x 2048-d region features, STTran PredCls forward "
+                               f"(enc 1 / dec 3 layers, d=1936), inputs resident in HBM",
+                   "clips_per_step": cps, "frames_per_clip": T, "boxes_per_frame": N, "pairs_per_step": P,
+                   "sharding": f"whole clips, {world} rank(s), RCCL all-gather of predictions" if world > 1
+                               else "single GPU"},
+    }
+
+    # ---- roofline of the dominant kernel: instrumented re-run of the same K steps -------------
+    if not args.no_roofline:
+        model.profile(True)
+        for _ in range(args.steps):
+            step()
+        prof = model.profile_read()
+        model.profile(False, reset=False)
+        g = prof["gemm"]
+        tot_ms = sum(v["ms"] for k, v in prof.items() if isinstance(v, dict))
+        ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        result["roofline"] = {
+            "kernel": "gemm_nt_kernel (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": ach,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "launches_per_step": g["launches"] / max(prof["forwards"], 1),
+            "avg_launch_us": 1e3 * g["ms"] / max(g["launches"], 1),
+            "share_of_device_time": g["ms"] / tot_ms if tot_ms else None,
+            "per_class_ms_per_step": {k: v["ms"] / max(prof["forwards"], 1) for k, v in prof.items()
+                                      if isinstance(v, dict) and v["launches"]},
+            "per_class_tflops": {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in prof.items()
+                                 if isinstance(v, dict) and v["ms"] > 0 and v["flops"] > 0},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(T, N, sd)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
