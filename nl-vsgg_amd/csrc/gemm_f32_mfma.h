@@ -18,7 +18,8 @@
 //     group of 8 is permuted identically for A and B, which leaves the dot product unchanged;
 //   * double-buffered LDS, global loads of tile t+1 are issued before the MFMAs of tile t and
 //     written to the other buffer after them: one barrier per K-step;
-//   * blockIdx is remapped so that workgroups sharing a weight panel sit on one XCD (its L2).
+//   * persistent workgroups on a stream-K schedule (equal MFMA work per CU, see below), remapped
+//     so that workgroups sharing a weight panel sit on one XCD (its L2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,14 +56,6 @@ struct EpiLinear {
     if (relu) v = fmaxf(v, 0.f);
     if (res) v += res[(int64_t)(res_rowidx ? res_rowidx[row] : row) * ldres + col];
     C[(int64_t)row * ldc + col] = v;
-  }
-};
-
-// split-K partial slab: slab[z][row][col]
-struct EpiSlab {
-  float* slab; int64_t ld; int64_t zstride;
-  __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    slab[(int64_t)blockIdx.z * zstride + (int64_t)row * ld + col] = v;
   }
 };
 
@@ -110,129 +103,186 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
+// ---- stream-K schedule ------------------------------------------------------------------------
+// The iteration space (output tile, K-step) is cut into gridDim.x equal contiguous ranges, one per
+// persistent workgroup, so every CU does the same number of MFMA steps whatever the tile count
+// (the plain one-tile-per-workgroup grid loses up to half the chip to wave quantisation at the
+// sizes of this path: e.g. 72 tiles of 256x256 for [2240,1936]x[1936,1936] on 256 CUs).
+// A workgroup that covers a tile's whole K range runs the epilogue itself; a partial range is
+// parked as raw accumulators in `slab` (at most two per workgroup: its first and its last tile) and
+// summed, in fixed workgroup order (deterministic), by gemm_fixup_kernel, which then runs the same
+// epilogue.  No inter-workgroup communication inside a launch.
+struct SkRange {
+  int64_t begin, end;
+};
+__host__ __device__ __forceinline__ SkRange sk_range(int b, int G, int64_t total) {
+  return SkRange{(int64_t)b * total / G, (int64_t)(b + 1) * total / G};
+}
+
 template <class T, class Epi>
 __global__ void __launch_bounds__(T::NT)
-gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int kchunk, int tiles_m, Epi epi) {
+gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps,
+               float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN;
-
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (logical % tiles_m) * BM;     // consecutive logical ids share the weight panel
-  const int n0 = (logical / tiles_m) * BN;
-  const int k_begin = blockIdx.z * kchunk;
-  const int k_end = min(K, k_begin + kchunk);
-  const int nsteps = (k_end - k_begin + kBK - 1) / kBK;
-
-  // ---- per-thread staging slots -------------------------------------------------------
-  const int kq4 = (tid & 7) * 4;
-  const float* pa[AV]; const float* pb[BV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) {
-    const int r = (tid >> 3) + i * (NT >> 3);
-    const int g = m0 + r;
-    pa[i] = (g < M) ? A.ptr + (int64_t)(A.rowidx ? A.rowidx[g] : g) * A.ld + kq4 : nullptr;
-  }
-#pragma unroll
-  for (int i = 0; i < BV; ++i) {
-    const int r = (tid >> 3) + i * (NT >> 3);
-    const int g = n0 + r;
-    pb[i] = (g < N) ? B.ptr + (int64_t)(B.rowidx ? B.rowidx[g] : g) * B.ld + kq4 : nullptr;
-  }
-  f32x4 ra[AV], rb[BV];
-  auto load_tile = [&](int k0) {
-    const bool kok = (k0 + kq4) < k_end;      // K is a multiple of 4: a float4 is all-in or all-out
-#pragma unroll
-    for (int i = 0; i < AV; ++i)
-      ra[i] = (pa[i] && kok) ? *reinterpret_cast<const f32x4*>(pa[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < BV; ++i)
-      rb[i] = (pb[i] && kok) ? *reinterpret_cast<const f32x4*>(pb[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto store_tile = [&](float* stage) {
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int r = (tid >> 3) + i * (NT >> 3);
-      *reinterpret_cast<f32x4*>(stage + r * kLdsStride + kq4) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BV; ++i) {
-      const int r = (tid >> 3) + i * (NT >> 3);
-      *reinterpret_cast<f32x4*>(stage + (BM + r) * kLdsStride + kq4) = rb[i];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   const int fr = lane & 31, fh = lane >> 5;
+  const int kq4 = (tid & 7) * 4;
   const int a_off = (wm * (BM / T::WM) + fr) * kLdsStride + fh * 4;
   const int b_off = (BM + wn * (BN / T::WN) + fr) * kLdsStride + fh * 4;
 
-  if (nsteps > 0) {
-    load_tile(k_begin);
-    store_tile(smem);
-  }
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    const float* cur = smem + (t & 1) * T::STAGE;
-    if (t + 1 < nsteps) load_tile(k_begin + (t + 1) * kBK);
+  const int G = gridDim.x;
+  const int blk = xcd_remap(blockIdx.x, G);      // neighbouring ranges (shared weight panels) on one XCD
+  const int64_t total = (int64_t)tiles * ksteps;
+  const SkRange rg = sk_range(blk, G, total);
+
+  for (int64_t it = rg.begin; it < rg.end;) {
+    const int tile = (int)(it / ksteps);
+    const int ks0 = (int)(it - (int64_t)tile * ksteps);
+    const int ks1 = (int)min((int64_t)ksteps, ks0 + (rg.end - it));
+    const int nsteps = ks1 - ks0;
+    const int m0 = (tile % tiles_m) * BM;          // consecutive tiles share the weight panel
+    const int n0 = (tile / tiles_m) * BN;
+    const int k_begin = ks0 * kBK;
+    const int k_end = min(K, ks1 * kBK);
+
+    const float* pa[AV]; const float* pb[BV];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      f32x4 fa[TM], fb[TN];
+    for (int i = 0; i < AV; ++i) {
+      const int g = m0 + (tid >> 3) + i * (NT >> 3);
+      pa[i] = (g < M) ? A.ptr + (int64_t)(A.rowidx ? A.rowidx[g] : g) * A.ld + kq4 : nullptr;
+    }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * kLdsStride + kb * 8);
+    for (int i = 0; i < BV; ++i) {
+      const int g = n0 + (tid >> 3) + i * (NT >> 3);
+      pb[i] = (g < N) ? B.ptr + (int64_t)(B.rowidx ? B.rowidx[g] : g) * B.ld + kq4 : nullptr;
+    }
+    f32x4 ra[AV], rb[BV];
+    auto load_tile = [&](int k0) {
+      const bool kok = (k0 + kq4) < k_end;      // K is a multiple of 4: a float4 is all-in or all-out
+#pragma unroll
+      for (int i = 0; i < AV; ++i)
+        ra[i] = (pa[i] && kok) ? *reinterpret_cast<const f32x4*>(pa[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < BV; ++i)
+        rb[i] = (pb[i] && kok) ? *reinterpret_cast<const f32x4*>(pb[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](float* stage) {
+#pragma unroll
+      for (int i = 0; i < AV; ++i)
+        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) = ra[i];
+#pragma unroll
+      for (int i = 0; i < BV; ++i)
+        *reinterpret_cast<f32x4*>(stage + (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * kLdsStride + kb * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tile(k_begin);
+    store_tile(smem);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+      const float* cur = smem + (t & 1) * T::STAGE;
+      if (t + 1 < nsteps) load_tile(k_begin + (t + 1) * kBK);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        f32x4 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * kLdsStride + kb * 8);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nsteps) store_tile(smem + ((t + 1) & 1) * T::STAGE);
-    __syncthreads();
-  }
-
-  // ---- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------------
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * kLdsStride + kb * 8);
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
-      const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = rbase + (e & 3) + 8 * (e >> 2);
-        if (row < M && col < N) epi(row, col, acc[i][j][e]);
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
       }
+      if (t + 1 < nsteps) store_tile(smem + ((t + 1) & 1) * T::STAGE);
+      __syncthreads();
     }
+
+    if (nsteps == ksteps) {
+      // ---- whole tile: epilogue.  C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
+          const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = rbase + (e & 3) + 8 * (e >> 2);
+            if (row < M && col < N) epi(row, col, acc[i][j][e]);
+          }
+        }
+      }
+    } else {
+      // ---- partial K range: park the raw accumulators (slot 0 = this workgroup's first tile,
+      //      slot 1 = its last), register-major so that every store is 256 contiguous bytes per wave
+      float* sp = slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN) + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sp[((i * TN + j) * 16 + e) * NT] = acc[i][j][e];
+    }
+    it += nsteps;
   }
 }
 
-// out = epi( sum_z slab[z] ), one thread per element
-template <class Epi>
-__global__ void __launch_bounds__(256)
-splitk_reduce_kernel(const float* slab, int splits, int M, int N, int64_t zstride, Epi epi) {
-  const int64_t total = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * zstride + i];
-    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
-    epi(row, col, s);
+// Sums the parked partial accumulators of every split tile in ascending workgroup order and runs
+// the epilogue.  grid = (tiles, TM*TN): one workgroup per 32x32-per-wave register group of a tile, so
+// the re-read of the parked data is spread over many CUs even when only a few tiles were split.
+// Tiles computed whole by one workgroup return at once.
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT)
+gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int G, const float* __restrict__ slab, Epi epi) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TN = T::TN;
+  const int tile = blockIdx.x;
+  const int64_t total = (int64_t)gridDim.x * ksteps;
+  const int64_t t0 = (int64_t)tile * ksteps, t1 = t0 + ksteps;
+  int b = (int)(t0 * G / total);
+  while (b > 0 && sk_range(b, G, total).begin > t0) --b;
+  while (sk_range(b, G, total).end <= t0) ++b;
+  {
+    const SkRange r = sk_range(b, G, total);
+    if (r.begin <= t0 && r.end >= t1) return;      // not split
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 31, fh = lane >> 5;
+  const int ij = blockIdx.y, i = ij / TN, j = ij % TN;
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (; b < G; ++b) {
+    const SkRange r = sk_range(b, G, total);
+    if (r.begin >= t1) break;
+    if (r.end <= r.begin) continue;
+    const float* sp = slab + ((int64_t)b * 2 + (r.begin >= t0 ? 0 : 1)) * (BM * BN) + (int64_t)ij * 16 * NT + tid;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += sp[e * NT];
+  }
+  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
+  const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = rbase + (e & 3) + 8 * (e >> 2);
+    if (row < M && col < N) epi(row, col, acc[e]);
   }
 }
 

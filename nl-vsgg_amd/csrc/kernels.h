@@ -13,6 +13,7 @@ enum { TILE_AUTO = 0, TILE_256x256 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_2
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
+size_t gemm_slab_floats_max();   // park space of the stream-K schedule, any tile
 
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                        const EpiLinear& epi, GemmPlan plan, float* slab);

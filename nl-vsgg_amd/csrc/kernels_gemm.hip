@@ -14,86 +14,101 @@ using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
 
 struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
-// eff = measured fraction of the fp32-MFMA peak a full grid of that tile sustains (see
-// DESIGN.md "GEMM tile planning"); used only to rank plans.
+// eff = fraction of the fp32-MFMA peak the tile's main loop sustains on a large square problem
+// (tools/gemm_bench.py --shapes big on MI355X: 127 / 125 / 112 / 121 / 115 TFLOP/s of 157.3);
+// blocks_per_cu = persistent workgroups per CU (bounded by LDS: 147 / 74 / 37 / 111 / 55 KB each).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 256, 0.80f, 1}, {128, 128, 0.72f, 2}, {64, 64, 0.50f, 4},
-    {256, 128, 0.76f, 1}, {128, 64, 0.62f, 3}};
+    {0, 0, 0.f, 0}, {256, 256, 0.81f, 1}, {128, 128, 0.79f, 2}, {64, 64, 0.71f, 4},
+    {256, 128, 0.77f, 1}, {128, 64, 0.73f, 2}};
 
-constexpr int kNumCU = 256;
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+static int grid_of(int tile, int64_t tiles, int64_t ksteps) {
+  const int64_t g = (int64_t)num_cus() * kTiles[tile].blocks_per_cu;
+  // never cut finer than 4 K-steps per workgroup: below that the per-segment prologue dominates
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, tiles * ksteps / 4));
+}
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split) {
+  (void)force_split;   // split-K is subsumed by the stream-K schedule
   GemmPlan best{TILE_128x128, 1};
   double best_t = 1e300;
+  const int64_t ksteps = (K + kBK - 1) / kBK;
   for (int t = 1; t < TILE_COUNT; ++t) {
     if (force_tile && t != force_tile) continue;
     const TileInfo& ti = kTiles[t];
-    const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn;
-    for (int sk = 1; sk <= 16; sk *= 2) {
-      if (force_split && sk != force_split) continue;
-      int64_t kchunk = ((K + sk - 1) / sk + kBK - 1) / kBK * kBK;
-      if (sk > 1 && kchunk * (sk - 1) >= K) continue;     // an empty split
-      if (sk > 1 && kchunk < 256) continue;
-      const int64_t blocks = tm * tn * sk;
-      const int64_t per_cu = (blocks + kNumCU - 1) / kNumCU;     // critical-path blocks on one CU
-      // MFMA time of one block (cycles on its CU) / efficiency
-      double t_blk = (double)ti.bm * ti.bn * kchunk * 2.0 / 256.0 / ti.eff;
-      double time = per_cu * t_blk + 6000.0;                      // + launch/prologue
-      if (sk > 1) time += 4000.0 + (double)M * N * (sk + 1) * 4.0 / (2000.0);  // slab write+reduce
-      if (time < best_t) { best_t = time; best = {t, sk}; }
-    }
+    const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
+    const int G = grid_of(t, tiles, ksteps);
+    const int cus = (int)std::min<int64_t>(G, num_cus());
+    // cycles on one CU: its equal share of the (padded) MFMA steps at the tile's efficiency ...
+    const double mfma = (double)tiles * ksteps / cus * ti.bm * ti.bn * kBK * 2.0 / 256.0 / ti.eff;
+    // ... plus parking and re-reading the partial tiles (~2 per workgroup) at ~2 KB/cycle chip-wide,
+    // the second launch, and the per-launch fixed cost
+    const bool split = (tiles % G) != 0;
+    const double fix = split ? 2.0 * std::min<int64_t>(2 * G, 2 * tiles) * ti.bm * ti.bn * 4.0 / 2000.0 + 5000.0 : 0.0;
+    const double time = mfma + fix + 6000.0;
+    if (time < best_t) { best_t = time; best = {t, 1}; }
   }
   return best;
 }
 
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N) {
-  return p.splitk > 1 ? (size_t)p.splitk * M * N : 0;
+  (void)M; (void)N;
+  const TileInfo& ti = kTiles[p.tile];
+  return (size_t)num_cus() * ti.blocks_per_cu * 2 * ti.bm * ti.bn;
+}
+
+size_t gemm_slab_floats_max() {
+  size_t m = 0;
+  for (int t = 1; t < TILE_COUNT; ++t) m = std::max(m, gemm_slab_floats(GemmPlan{t, 1}, 0, 0));
+  return m;
 }
 
 template <class T, class Epi>
-static hipError_t launch_tile(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                              int splitk, const Epi& epi) {
+static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
+                              int K, float* slab, const Epi& epi) {
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<T, Epi>;
+  auto kern = gemm_sk_kernel<T, Epi>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN;
-  const int kchunk = ((K + splitk - 1) / splitk + kBK - 1) / kBK * kBK;
-  dim3 grid(tm * tn, 1, splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, kchunk, tm, epi);
+  const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
+  const int ksteps = (K + kBK - 1) / kBK;
+  const int G = grid_of(tile_id, tiles, ksteps);
+  const int64_t total = (int64_t)tiles * ksteps;
+  bool split = false;
+  for (int b = 1; b < G && !split; ++b) split = (sk_range(b, G, total).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, slab, epi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !split) return e;
+  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(tiles, T::TM * T::TN), dim3(T::NT), 0, s, M, N, tm, ksteps, G, slab, epi);
   return hipGetLastError();
-}
-
-template <class Epi>
-static hipError_t launch_any(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                             int tile, int splitk, const Epi& epi) {
-  switch (tile) {
-    case TILE_256x256: return launch_tile<T256x256, Epi>(s, A, B, M, N, K, splitk, epi);
-    case TILE_256x128: return launch_tile<T256x128, Epi>(s, A, B, M, N, K, splitk, epi);
-    case TILE_128x128: return launch_tile<T128x128, Epi>(s, A, B, M, N, K, splitk, epi);
-    case TILE_128x64: return launch_tile<T128x64, Epi>(s, A, B, M, N, K, splitk, epi);
-    default: return launch_tile<T64x64, Epi>(s, A, B, M, N, K, splitk, epi);
-  }
 }
 
 template <class Epi>
 static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                                const Epi& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
-  if (plan.splitk <= 1) return launch_any<Epi>(s, A, B, M, N, K, plan.tile, 1, epi);
-  if (!slab) return hipErrorInvalidValue;
-  EpiSlab es{slab, (int64_t)N, (int64_t)M * N};
-  hipError_t e = launch_any<EpiSlab>(s, A, B, M, N, K, plan.tile, plan.splitk, es);
-  if (e != hipSuccess) return e;
-  const int64_t total = (int64_t)M * N;
-  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL((splitk_reduce_kernel<Epi>), dim3(blocks), dim3(256), 0, s, slab, plan.splitk, M, N,
-                     (int64_t)M * N, epi);
-  return hipGetLastError();
+  switch (plan.tile) {
+    case TILE_256x256: return launch_tile<T256x256, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_256x128: return launch_tile<T256x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_128x128: return launch_tile<T128x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_128x64: return launch_tile<T128x64, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    default: return launch_tile<T64x64, Epi>(s, TILE_64x64, A, B, M, N, K, slab, epi);
+  }
 }
 
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,

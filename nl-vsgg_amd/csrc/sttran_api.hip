@@ -200,10 +200,9 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
                int force_tile = 0, int force_split = 0) {
   if (M <= 0) return STTRAN_OK;
   GemmPlan plan = plan_gemm(M, N, K, force_tile, force_split);
-  size_t sf = gemm_slab_floats(plan, M, N);
-  if (sf * 4 > h->slab.bytes) {
+  if (gemm_slab_floats_max() * 4 > h->slab.bytes) {
     HIPCK(hipStreamSynchronize(s));
-    HIPCK(h->slab.ensure(sf * 4));
+    HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
   }
   GemmOperand B{Wt, (int64_t)K, nullptr};
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
@@ -222,6 +221,7 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   HIPCK(hipDeviceSynchronize());
   const int64_t cp = std::max(P, h->capP), cb = std::max(B, h->capB);
   const int64_t D = h->cfg.embed_dim, F = h->cfg.ffn_dim, tok = 2 * cp;
+  HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
   HIPCK(h->x0.ensure((size_t)cp * D * 4));
   HIPCK(h->ebuf.ensure((size_t)cp * D * 4));
   HIPCK(h->qkv.ensure((size_t)tok * 3 * D * 4));
@@ -624,7 +624,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     EpiConvRelBn e{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
     HIPCK(gemm_conv(s, GemmOperand{W(h, "conv.4.weight"), K, nullptr}, GemmOperand{COLS, K, nullptr}, M, N, K, e,
-                    plan, nullptr));
+                    plan, h->slab.as<float>()));
   }
   {
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
@@ -712,7 +712,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     GemmPlan plan = plan_gemm(P, nh, D, TILE_64x64, 1);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D));
     HIPCK(gemm_heads(s, GemmOperand{UNI, D, out_src}, GemmOperand{h->heads_w, D, nullptr}, (int)P, nh, D, eh, plan,
-                     nullptr));
+                     h->slab.as<float>()));
   }
   if (h->prof_on) h->prof.forwards += 1;
   return STTRAN_OK;
@@ -738,14 +738,13 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, 
   if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3)) return STTRAN_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   GemmPlan plan = plan_gemm(M, N, K, tile_cfg, split_k);
-  float* slab = nullptr;
-  size_t sf = gemm_slab_floats(plan, M, N);
-  if (sf && hipMalloc(reinterpret_cast<void**>(&slab), sf * 4) != hipSuccess) return STTRAN_ERR_HIP;
+  static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
+  if (!slab && hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_floats_max() * 4) != hipSuccess)
+    return STTRAN_ERR_HIP;
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
   hipError_t err = gemm_linear(s, GemmOperand{A, K, a_rowidx}, GemmOperand{Wt, K, nullptr}, (int)M, (int)N, (int)K,
                                e, plan, slab);
-  if (slab) { hipStreamSynchronize(s); hipFree(slab); }
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fp32 MFMA GEMM (sttran_debug_gemm) per (shape, tile, split-K).
+Used to tune the tile planner (csrc/kernels_gemm.hip); run on the GPU box:
+    python tools/gemm_bench.py [--shapes big|path64|path16|path16x8] [--tiles 1,2,3,4,5]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nl_vsgg_amd import _native  # noqa: E402
+
+TILES = {1: "256x256", 2: "128x128", 3: "64x64", 4: "256x128", 5: "128x64"}
+
+
+def path_shapes(P, NT):
+    D, F = 1936, 2048
+    return [("fc", P, 512, 2048), ("conv", 256, P * 49, 1152), ("vr_fc", P, 512, 12544),
+            ("enc_qkv", P, 3 * D, D), ("enc_out", P, D, D), ("enc_ffn1", P, F, D), ("enc_ffn2", P, D, F),
+            ("dec_qkv", NT, 3 * D, D), ("dec_out", NT, D, D), ("dec_ffn1", NT, F, D), ("dec_ffn2", NT, D, F),
+            ("heads", P, 26, D)]
+
+
+SHAPES = {
+    "big": [("sq4096", 4096, 4096, 4096), ("sq8192x2048", 8192, 8192, 2048)],
+    "path64": path_shapes(2240, 4410),
+    "path16": path_shapes(176, 330),
+    "path16x8": path_shapes(1408, 2640),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="big")
+    ap.add_argument("--tiles", default="1,2,3,4,5")
+    ap.add_argument("--splits", default="1,2,4,8")
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    lib = _native.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for name, M, N, K in SHAPES[a.shapes]:
+        A = torch.randn(M, K, device="cuda")
+        W = torch.randn(N, K, device="cuda")
+        b = torch.randn(N, device="cuda")
+        Cc = torch.empty(M, N, device="cuda")
+        best = None
+        rows = []
+        for tile in [0] + [int(t) for t in a.tiles.split(",")]:
+            for split in ([0] if tile == 0 else [int(s) for s in a.splits.split(",")]):
+                if split > 1 and K // split < 256:
+                    continue
+                for _ in range(2):
+                    lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / a.iters
+                tf = 2.0 * M * N * K / us / 1e6
+                rows.append((tile, split, us, tf))
+                if tile and (best is None or us < best[2]):
+                    best = (tile, split, us, tf)
+        auto = rows[0]
+        print(f"{name:10s} M={M:6d} N={N:6d} K={K:5d}  auto {auto[2]:9.1f} us {auto[3]:6.1f} TF | best "
+              f"{TILES[best[0]]}/s{best[1]} {best[2]:9.1f} us {best[3]:6.1f} TF")
+        print("     " + "  ".join(f"{TILES[t]}/s{s}:{tf:5.1f}" for t, s, us, tf in rows[1:]))
+
+
+if __name__ == "__main__":
+    main()
