@@ -152,6 +152,8 @@ int sttran_profile_read(SttranHandle* h, SttranProfile* out); /* synchronises th
 int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* W, const float* bias,
                       const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                       int32_t relu, int32_t tile_cfg, int32_t split_k, void* stream);
+/* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
+int sttran_debug_mfma_peak(int32_t iters, double* tflops);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */
 int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                            int64_t rows, int64_t dim, void* stream);

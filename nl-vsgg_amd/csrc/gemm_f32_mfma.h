@@ -107,7 +107,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // The iteration space (output tile, K-step) is cut into gridDim.x equal contiguous ranges, one per
 // persistent workgroup, so every CU does the same number of MFMA steps whatever the tile count
 // (the plain one-tile-per-workgroup grid loses up to half the chip to wave quantisation at the
-// sizes of this path: e.g. 72 tiles of 256x256 for [2240,1936]x[1936,1936] on 256 CUs).
+// sizes of this path: e.g. 288 tiles of 128x128 for [2240,1936]x[1936,1936] on 256 CUs x 2 workgroups).
 // A workgroup that covers a tile's whole K range runs the epilogue itself; a partial range is
 // parked as raw accumulators in `slab` (at most two per workgroup: its first and its last tile) and
 // summed, in fixed workgroup order (deterministic), by gemm_fixup_kernel, which then runs the same
@@ -119,7 +119,7 @@ __host__ __device__ __forceinline__ SkRange sk_range(int b, int G, int64_t total
   return SkRange{(int64_t)b * total / G, (int64_t)(b + 1) * total / G};
 }
 
-template <class T, class Epi>
+template <class T, class Epi, int PIPE>
 __global__ void __launch_bounds__(T::NT)
 gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps,
                float* __restrict__ slab, Epi epi) {
@@ -149,34 +149,53 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     const int k_begin = ks0 * kBK;
     const int k_end = min(K, ks1 * kBK);
 
+    // Staging slots.  Rows past M/N and the K tail are loaded from a valid address (row 0 / k 0) and
+    // zeroed by a select, so the loads stay unconditional (no exec-mask branches in the loop).
     const float* pa[AV]; const float* pb[BV];
+    bool va[AV], vb[BV];
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + (tid >> 3) + i * (NT >> 3);
-      pa[i] = (g < M) ? A.ptr + (int64_t)(A.rowidx ? A.rowidx[g] : g) * A.ld + kq4 : nullptr;
+      va[i] = g < M;
+      pa[i] = A.ptr + (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld;
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
       const int g = n0 + (tid >> 3) + i * (NT >> 3);
-      pb[i] = (g < N) ? B.ptr + (int64_t)(B.rowidx ? B.rowidx[g] : g) * B.ld + kq4 : nullptr;
+      vb[i] = g < N;
+      pb[i] = B.ptr + (int64_t)(vb[i] ? (B.rowidx ? B.rowidx[g] : g) : 0) * B.ld;
     }
     f32x4 ra[AV], rb[BV];
+    bool kok_loaded = true;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tile = [&](int k0) {
-      const bool kok = (k0 + kq4) < k_end;      // K is a multiple of 4: a float4 is all-in or all-out
+      kok_loaded = (k0 + kq4) < k_end;          // K is a multiple of 4: a float4 is all-in or all-out
+      const int ko = kok_loaded ? k0 + kq4 : 0;
 #pragma unroll
-      for (int i = 0; i < AV; ++i)
-        ra[i] = (pa[i] && kok) ? *reinterpret_cast<const f32x4*>(pa[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + ko);
 #pragma unroll
-      for (int i = 0; i < BV; ++i)
-        rb[i] = (pb[i] && kok) ? *reinterpret_cast<const f32x4*>(pb[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + ko);
     };
+    // the zero-select happens here, at the LDS write, so that the wait for the global loads sits
+    // after the MFMAs of the current step and not right behind the load issue
     auto store_tile = [&](float* stage) {
 #pragma unroll
       for (int i = 0; i < AV; ++i)
-        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) = ra[i];
+        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) =
+            (va[i] && kok_loaded) ? ra[i] : zero4;
 #pragma unroll
       for (int i = 0; i < BV; ++i)
-        *reinterpret_cast<f32x4*>(stage + (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) = rb[i];
+        *reinterpret_cast<f32x4*>(stage + (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) =
+            (vb[i] && kok_loaded) ? rb[i] : zero4;
+    };
+    // fragment group kb of a stage: k = kb*8 + 4*(lane>>5) + {0..3} for A rows and W rows alike
+    auto read_frags = [&](const float* stage, int kb, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(stage + a_off + i * 32 * kLdsStride + kb * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(stage + b_off + j * 32 * kLdsStride + kb * 8);
     };
 
     f32x16 acc[TM][TN];
@@ -186,32 +205,122 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
 
     load_tile(k_begin);
     store_tile(smem);
     __syncthreads();
-    for (int t = 0; t < nsteps; ++t) {
-      const float* cur = smem + (t & 1) * T::STAGE;
-      if (t + 1 < nsteps) load_tile(k_begin + (t + 1) * kBK);
+    if constexpr (PIPE == 0) {
+      // plain loop: fragments of group kb are read right before its MFMAs (the compiler's own
+      // lgkmcnt ladder), one barrier per K-step
+      f32x4 fa[TM], fb[TN];
+      for (int t = 0; t < nsteps; ++t) {
+        const float* cur = smem + (t & 1) * T::STAGE;
+        const bool more = t + 1 < nsteps;
+        if (more) load_tile(k_begin + (t + 1) * kBK);
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        f32x4 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * kLdsStride + kb * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const f32x4*>(cur + b_off + j * 32 * kLdsStride + kb * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+          read_frags(cur, kb, fa, fb);
+          mma(fa, fb);
+        }
+        if (more) store_tile(smem + ((t + 1) & 1) * T::STAGE);
+        __syncthreads();
       }
-      if (t + 1 < nsteps) store_tile(smem + ((t + 1) & 1) * T::STAGE);
-      __syncthreads();
+    } else {
+      // Software pipeline: fragment group kb+1 is read from LDS while the MFMAs of group kb run, and
+      // the last group of a K-step is held in registers across the barrier, so its 4*TM*TN MFMAs
+      // cover the barrier wait and the LDS latency of the next step's first fragment read.
+      // The staging work is spread one piece per MFMA gap (an MFMA occupies the matrix pipe for 64
+      // cycles but the issue port for 8): group 0 carries the global loads of the next tile, group 2
+      // carries their select + ds_write, so neither costs issue time of its own.  Loads and stores
+      // run on the last step too (from a clamped address, into the idle buffer): no branches.
+      f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+      read_frags(smem, 0, fa0, fb0);
+      for (int t = 0; t < nsteps; ++t) {
+        const float* cur = smem + (t & 1) * T::STAGE;
+        float* nxt = smem + ((t + 1) & 1) * T::STAGE;
+        const int k0 = k_begin + (t + 1) * kBK;
+        kok_loaded = (k0 + kq4) < k_end;
+        const int ko = kok_loaded ? k0 + kq4 : 0;
+        read_frags(cur, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          int n = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ko);
+                else if (n < AV + BV) rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + ko);
+                ++n;
+              }
+#pragma unroll
+          for (; n < AV + BV; ++n) {       // tiles with fewer MFMAs than loads
+            if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ko);
+            else rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + ko);
+          }
+          // one global load per MFMA gap (sched_group_barrier masks: 0x8 MFMA, 0x20 VMEM read)
+#pragma unroll
+          for (int q = 0; q < AV + BV && q < 4 * TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 2, fa0, fb0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 3, fa1, fb1);
+        {
+          int n = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                if (n < AV)
+                  *reinterpret_cast<f32x4*>(nxt + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
+                      (va[n] && kok_loaded) ? ra[n] : zero4;
+                else if (n < AV + BV)
+                  *reinterpret_cast<f32x4*>(nxt + (BM + (tid >> 3) + (n - AV) * (NT >> 3)) * kLdsStride + kq4) =
+                      (vb[n - AV] && kok_loaded) ? rb[n - AV] : zero4;
+                ++n;
+              }
+#pragma unroll
+          for (; n < AV + BV; ++n) {
+            if (n < AV)
+              *reinterpret_cast<f32x4*>(nxt + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
+                  (va[n] && kok_loaded) ? ra[n] : zero4;
+            else
+              *reinterpret_cast<f32x4*>(nxt + (BM + (tid >> 3) + (n - AV) * (NT >> 3)) * kLdsStride + kq4) =
+                  (vb[n - AV] && kok_loaded) ? rb[n - AV] : zero4;
+          }
+          // one select + ds_write per MFMA gap (0x2 VALU, 0x200 DS write)
+#pragma unroll
+          for (int q = 0; q < AV + BV && q < 4 * TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x2, 4, 1);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(nxt, 0, fa0, fb0);
+        mma(fa1, fb1);
+      }
     }
 
     if (nsteps == ksteps) {

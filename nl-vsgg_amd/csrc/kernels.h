@@ -8,8 +8,7 @@
 namespace sttran {
 
 // ---- GEMM ------------------------------------------------------------------------------
-enum { TILE_AUTO = 0, TILE_256x256 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_256x128 = 4, TILE_128x64 = 5,
-       TILE_COUNT = 6 };
+enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_COUNT = 5 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
@@ -21,6 +20,8 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
                       const EpiHeads& epi, GemmPlan plan, float* slab);
 hipError_t gemm_conv(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                      const EpiConvRelBn& epi, GemmPlan plan, float* slab);
+
+hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // pair_idx/labels (int64) -> int32 gather indices + the two class-embedding column blocks of x

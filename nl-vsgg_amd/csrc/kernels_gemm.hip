@@ -7,7 +7,6 @@
 
 namespace sttran {
 
-using T256x256 = GemmTile<256, 256, 4, 2>;   // 8 waves, wave tile 64x128 (2x4 MFMA tiles)
 using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
@@ -15,11 +14,10 @@ using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
 
 struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // eff = fraction of the fp32-MFMA peak the tile's main loop sustains on a large square problem
-// (tools/gemm_bench.py --shapes big on MI355X: 127 / 125 / 112 / 121 / 115 TFLOP/s of 157.3);
-// blocks_per_cu = persistent workgroups per CU (bounded by LDS: 147 / 74 / 37 / 111 / 55 KB each).
+// (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
+// (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 256, 0.81f, 1}, {128, 128, 0.79f, 2}, {64, 64, 0.71f, 4},
-    {256, 128, 0.77f, 1}, {128, 64, 0.73f, 2}};
+    {0, 0, 0.f, 0}, {256, 128, 0.85f, 1}, {128, 128, 0.83f, 2}, {64, 64, 0.74f, 4}, {128, 64, 0.77f, 2}};
 
 static int num_cus() {
   static int n = 0;
@@ -73,11 +71,15 @@ size_t gemm_slab_floats_max() {
   return m;
 }
 
-template <class T, class Epi>
-static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
-                              int K, float* slab, const Epi& epi) {
+#ifndef STTRAN_GEMM_PIPE
+#define STTRAN_GEMM_PIPE 1
+#endif
+
+template <class T, class Epi, int PIPE>
+static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
+                                int K, float* slab, const Epi& epi) {
   static bool attr_set = false;
-  auto kern = gemm_sk_kernel<T, Epi>;
+  auto kern = gemm_sk_kernel<T, Epi, PIPE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
@@ -98,12 +100,26 @@ static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, 
   return hipGetLastError();
 }
 
+template <class T, class Epi>
+static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
+                              int K, float* slab, const Epi& epi) {
+#ifdef STTRAN_GEMM_EXPERIMENT
+  // build-time experiment switch (tools/gemm_bench.py): pick the main-loop variant at run time
+  const char* v = getenv("STTRAN_GEMM_PIPE");
+  const int pipe = v ? atoi(v) : STTRAN_GEMM_PIPE;
+  if (pipe == 1) return launch_tile_p<T, Epi, 1>(s, tile_id, A, B, M, N, K, slab, epi);
+  if (pipe == 2) return launch_tile_p<T, Epi, 2>(s, tile_id, A, B, M, N, K, slab, epi);
+  return launch_tile_p<T, Epi, 0>(s, tile_id, A, B, M, N, K, slab, epi);
+#else
+  return launch_tile_p<T, Epi, STTRAN_GEMM_PIPE>(s, tile_id, A, B, M, N, K, slab, epi);
+#endif
+}
+
 template <class Epi>
 static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                                const Epi& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
   switch (plan.tile) {
-    case TILE_256x256: return launch_tile<T256x256, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
     case TILE_256x128: return launch_tile<T256x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
     case TILE_128x128: return launch_tile<T128x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
     case TILE_128x64: return launch_tile<T128x64, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
@@ -122,6 +138,31 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
 hipError_t gemm_conv(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                      const EpiConvRelBn& epi, GemmPlan plan, float* slab) {
   return gemm_generic<EpiConvRelBn>(s, A, B, M, N, K, epi, plan, slab);
+}
+
+// ---- calibration: back-to-back v_mfma_f32_32x32x2_f32 on independent accumulators, no memory ----
+// Gives the fp32-MFMA rate THIS device sustains (clock under load differs between MI355X boards by
+// several per cent), the yardstick tools/gemm_bench.py normalises against.
+__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 1.f; a2[e] = 2.f; a3[e] = 3.f; }
+  float x = threadIdx.x * 1e-3f, y = 1.0f + blockIdx.x * 1e-6f;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
+  if (s == 12345.678f) out[0] = s;     // keep the chain alive
+}
+
+hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, s, out, iters);
+  return hipGetLastError();
 }
 
 }  // namespace sttran

@@ -748,6 +748,27 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, 
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
+  if (iters <= 0 || !tflops) return STTRAN_ERR_INVALID;
+  float* out = nullptr;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&out), 256) != hipSuccess) return STTRAN_ERR_HIP;
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  launch_mfma_peak(nullptr, out, iters, ncu);            // warm-up
+  hipEventRecord(a, nullptr);
+  launch_mfma_peak(nullptr, out, iters, ncu);
+  hipEventRecord(b, nullptr);
+  hipEventSynchronize(b);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(out);
+  // per block: 4 waves x iters x 4 MFMAs x (32*32*2*2 flops)
+  *tflops = (double)ncu * 4.0 * iters * 4.0 * 4096.0 / (ms * 1e-3) / 1e12;
+  return STTRAN_OK;
+}
+
 int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
                            int64_t dim, void* stream) {
   if (!x || !gamma || !beta || !y) return STTRAN_ERR_INVALID;

@@ -49,7 +49,7 @@ SHAPES = [(1, 1, 4), (2, 3872, 1936), (33, 70, 100), (176, 512, 2048), (330, 580
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 def test_gemm_tiles(lib, M, N, K, tile):
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
     A = torch.randn(M, K, device="cuda", generator=g)

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nl_vsgg_amd import _native  # noqa: E402
 
-TILES = {1: "256x256", 2: "128x128", 3: "64x64", 4: "256x128", 5: "128x64"}
+TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64"}
 
 
 def path_shapes(P, NT):
@@ -34,23 +34,30 @@ SHAPES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="big")
-    ap.add_argument("--tiles", default="1,2,3,4,5")
-    ap.add_argument("--splits", default="1,2,4,8")
+    ap.add_argument("--tiles", default="1,2,3,4")
+    ap.add_argument("--pipes", default="0", help="main-loop variants (library built with EXTRA=-DSTTRAN_GEMM_EXPERIMENT)")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--zeros", action="store_true", help="zero operands: separates clock (power) limits from schedule limits")
     a = ap.parse_args()
     lib = _native.load()
     p = lambda t: C.c_void_p(t.data_ptr())
+    torch.zeros(1, device="cuda")
+    pk = C.c_double()
+    for _ in range(3):
+        lib.sttran_debug_mfma_peak(20000, C.byref(pk))
+    print(f"device fp32-MFMA rate (register-only loop): {pk.value:.1f} TFLOP/s (spec peak 157.3)")
     for name, M, N, K in SHAPES[a.shapes]:
         A = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda")
+        if a.zeros:
+            A.zero_(); W.zero_()
         b = torch.randn(N, device="cuda")
         Cc = torch.empty(M, N, device="cuda")
         best = None
         rows = []
         for tile in [0] + [int(t) for t in a.tiles.split(",")]:
-            for split in ([0] if tile == 0 else [int(s) for s in a.splits.split(",")]):
-                if split > 1 and K // split < 256:
-                    continue
+            for split in ([0] if tile == 0 else [int(s) for s in a.pipes.split(",")]):
+                os.environ["STTRAN_GEMM_PIPE"] = str(split)     # only read by EXPERIMENT builds
                 for _ in range(2):
                     lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
                 torch.cuda.synchronize()
@@ -67,8 +74,8 @@ def main():
                     best = (tile, split, us, tf)
         auto = rows[0]
         print(f"{name:10s} M={M:6d} N={N:6d} K={K:5d}  auto {auto[2]:9.1f} us {auto[3]:6.1f} TF | best "
-              f"{TILES[best[0]]}/s{best[1]} {best[2]:9.1f} us {best[3]:6.1f} TF")
-        print("     " + "  ".join(f"{TILES[t]}/s{s}:{tf:5.1f}" for t, s, us, tf in rows[1:]))
+              f"{TILES[best[0]]}/p{best[1]} {best[2]:9.1f} us {best[3]:6.1f} TF")
+        print("     " + "  ".join(f"{TILES[t]}/p{s}:{tf:5.1f}" for t, s, us, tf in rows[1:]))
 
 
 if __name__ == "__main__":
