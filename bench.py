@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+from nl_vsgg_amd.lib.distributed import pack_predictions  # noqa: E402
 from nl_vsgg_amd.lib.sttran import STTran, pack_clips  # noqa: E402
 
 CLASSES = ["__background__"] + [f"c{i}" for i in range(36)]
@@ -114,9 +115,7 @@ def main():
     def step():
         pred = model(batch)
         if world > 1:     # per-clip predictions of every rank, one fixed-size RCCL all-gather
-            mine = torch.cat([pred["attention_distribution"], pred["spatial_distribution"],
-                              pred["contacting_distribution"]], dim=1)
-            dist.all_gather_into_tensor(gathered, mine)
+            dist.all_gather_into_tensor(gathered, pack_predictions(pred))
         return pred
 
     def barrier():

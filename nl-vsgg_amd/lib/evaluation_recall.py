@@ -1,0 +1,239 @@
+"""Recall@K evaluation of per-clip predictions -- the consumer of the hot path's output dict.
+
+Host-side (numpy) counterpart of the reference's `lib/evaluation_recall.py::SceneGraphEvaluator`
+(`:374-465`), written from its scoring contract so that the recall numbers
+of both implementations are identical on the same predictions (`tests/test_evaluator.py` checks this
+against values captured from the reference, `tests/golden/eval_*.json`).
+
+    ev = SceneGraphEvaluator(mode='predcls', AG_object_classes=..., AG_all_predicates=...,
+                             AG_attention_predicates=..., AG_spatial_predicates=...,
+                             AG_contacting_predicates=..., iou_threshold=0.5)
+    ev.register_container()
+    ev.evaluate_scene_graph(gt_annotation, pred)     # once per clip
+    ev.calculate_mean_recall(); ev.print_stats(logger)
+
+Five metrics are accumulated in `result_dict` under the reference's keys:
+`<mode>_recall` (with graph constraint), `_recall_nogc`, `_semi_recall`, `_mean_recall`,
+`_ng_mean_recall` (+ their `_collect` / `_list` helpers).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KS = (10, 20, 50)
+
+
+def _np(x):
+    """torch tensor / list / ndarray -> ndarray on the host."""
+    if hasattr(x, "detach"):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def box_iou_plus1(box, boxes):
+    """IoU of one box with many, areas measured with the +1-pixel convention and float64
+    arithmetic (`lib/fpn/box_intersections_cpu/bbox.pyx:21-61`)."""
+    box = np.asarray(box, dtype=np.float64)
+    boxes = np.asarray(boxes, dtype=np.float64)
+    iw = np.minimum(box[2], boxes[:, 2]) - np.maximum(box[0], boxes[:, 0]) + 1.0
+    ih = np.minimum(box[3], boxes[:, 3]) - np.maximum(box[1], boxes[:, 1]) + 1.0
+    inter = iw * ih
+    area_a = (box[2] - box[0] + 1.0) * (box[3] - box[1] + 1.0)
+    area_b = (boxes[:, 2] - boxes[:, 0] + 1.0) * (boxes[:, 3] - boxes[:, 1] + 1.0)
+    iou = inter / (area_a + area_b - inter)
+    return np.where((iw > 0) & (ih > 0), iou, 0.0)
+
+
+def _triplets(rels, classes, boxes):
+    """(class_s, predicate, class_o) rows and the 8-number (subject box | object box) rows."""
+    so = classes[rels[:, :2]]
+    trip = np.column_stack((so[:, 0], rels[:, 2], so[:, 1]))
+    tb = np.column_stack((boxes[rels[:, 0]], boxes[rels[:, 1]]))
+    return trip, tb
+
+
+def match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, pred_boxes, pred_classes, predicate_scores,
+                      obj_scores, iou_thresh=0.5):
+    """For every prediction (in descending order of subj_score * obj_score * predicate_score) the
+    list of ground-truth relations it hits: equal class triple and both box IoUs >= iou_thresh
+    (`lib/evaluation_recall.py:630-695,731-773`)."""
+    if pred_rels.size == 0:
+        return [[]]
+    gt_trip, gt_tb = _triplets(gt_rels, gt_classes, gt_boxes)
+    pr_trip, pr_tb = _triplets(pred_rels, pred_classes, pred_boxes)
+    score = obj_scores[pred_rels[:, 0]] * obj_scores[pred_rels[:, 1]] * predicate_scores
+    order = score.argsort()[::-1]                     # same primitive as the reference: ties resolve alike
+    pr_trip, pr_tb = pr_trip[order], pr_tb[order]
+    hits = [[] for _ in range(pr_trip.shape[0])]
+    same = (gt_trip[:, None, :] == pr_trip[None, :, :]).all(axis=2)      # [n_gt, n_pred]
+    for g in np.nonzero(same.any(axis=1))[0]:
+        cand = np.nonzero(same[g])[0]
+        gb = np.asarray(gt_tb[g], dtype=np.float32)    # the reference rounds through float32 here
+        pb = np.asarray(pr_tb[cand], dtype=np.float32)
+        ok = (box_iou_plus1(gb[:4], pb[:, :4]) >= iou_thresh) & (box_iou_plus1(gb[4:], pb[:, 4:]) >= iou_thresh)
+        for i in cand[ok]:
+            hits[i].append(int(g))
+    return hits
+
+
+def _recall_at(hits, n_gt):
+    out = {}
+    for k in KS:
+        got = set()
+        for h in hits[:k]:
+            got.update(h)
+        out[k] = (float(len(got)) / float(n_gt), sorted(got))
+    return out
+
+
+class SceneGraphEvaluator:
+    def __init__(self, mode, AG_object_classes, AG_all_predicates, AG_attention_predicates, AG_spatial_predicates,
+                 AG_contacting_predicates, iou_threshold=0.5, constraint=False, semithreshold=None):
+        self.mode = mode
+        self.result_dict = {}
+        self.subject_category = 1
+        self.iou_threshold = iou_threshold
+        self.AG_object_classes = AG_object_classes
+        self.AG_all_predicates = list(AG_all_predicates)
+        self.AG_attention_predicates = list(AG_attention_predicates)
+        self.AG_spatial_predicates = list(AG_spatial_predicates)
+        self.AG_contacting_predicates = list(AG_contacting_predicates)
+        self.semithreshold = semithreshold
+        self.num_rel = len(self.AG_all_predicates)
+        self._att_ix = [self.AG_all_predicates.index(p) for p in self.AG_attention_predicates]
+        self._spa_ix = [self.AG_all_predicates.index(p) for p in self.AG_spatial_predicates]
+        self._con_ix = [self.AG_all_predicates.index(p) for p in self.AG_contacting_predicates]
+
+    # ---- containers --------------------------------------------------------------------------
+    def register_container(self):
+        m = self.mode
+        for t in ("recall", "recall_nogc", "semi_recall"):
+            self.result_dict[f"{m}_{t}"] = {k: [] for k in KS}
+        for t in ("mean_recall", "ng_mean_recall"):
+            self.result_dict[f"{m}_{t}"] = {k: 0.0 for k in KS}
+            self.result_dict[f"{m}_{t}_collect"] = {k: [[] for _ in range(self.num_rel)] for k in KS}
+            self.result_dict[f"{m}_{t}_list"] = {k: [] for k in KS}
+
+    # ---- per-clip accumulation ------------------------------------------------------------------
+    def evaluate_scene_graph(self, gt, pred):
+        """`gt`: list over frames of `[ {'person_bbox'}, {'class','bbox','attention_relationship',
+        'spatial_relationship','contacting_relationship'}, ... ]` (AG_Test schema,
+        `dataloader/wk_action_genome.py:281-292`); `pred`: the dict returned by `STTran.forward`.
+        Frame `i` of `gt` is matched with the pairs whose `im_idx == i`."""
+        att = _np(pred["attention_distribution"]).astype(np.float32)
+        att = att - att.max(axis=1, keepdims=True)      # softmax over the 3 attention logits (:400)
+        att = np.exp(att)
+        att = att / att.sum(axis=1, keepdims=True)
+        spa = _np(pred["spatial_distribution"])
+        con = _np(pred["contacting_distribution"])
+        pair_idx = _np(pred["pair_idx"])
+        im_idx = _np(pred["im_idx"])
+        boxes = _np(pred["boxes"])[:, 1:]
+        if self.mode == "predcls":
+            classes, obj_scores = _np(pred["labels"]), _np(pred["scores"])
+        else:
+            classes, obj_scores = _np(pred["pred_labels"]), _np(pred["pred_scores"])
+        na, ns, nc = att.shape[1], spa.shape[1], con.shape[1]
+        for idx, frame_gt in enumerate(gt):
+            n_obj = len(frame_gt) - 1
+            gt_boxes = np.zeros((n_obj + 1, 4))
+            gt_classes = np.zeros(n_obj + 1)
+            gt_boxes[0] = np.asarray(_np(frame_gt[0]["person_bbox"])).reshape(-1)[:4]
+            gt_classes[0] = self.subject_category
+            gt_rels = []
+            for m, obj in enumerate(frame_gt[1:], start=1):
+                gt_boxes[m] = _np(obj["bbox"])
+                gt_classes[m] = obj["class"]
+                a = int(np.asarray(_np(obj["attention_relationship"])).reshape(-1)[0])
+                gt_rels.append([0, m, self._att_ix[a]])                       # <human, object>
+                for sp in np.asarray(_np(obj["spatial_relationship"])).reshape(-1).tolist():
+                    gt_rels.append([m, 0, self._spa_ix[int(sp)]])             # <object, human>
+                for ct in np.asarray(_np(obj["contacting_relationship"])).reshape(-1).tolist():
+                    gt_rels.append([0, m, self._con_ix[int(ct)]])
+            gt_rels = np.array(gt_rels)
+            sel = im_idx == idx
+            pi = pair_idx[sel]
+            n = pi.shape[0]
+            rels = np.concatenate((pi, pi[:, ::-1], pi), axis=0)             # attention | spatial (reversed) | contact
+            scores = np.zeros((3 * n, na + ns + nc))
+            scores[:n, :na] = att[sel]
+            scores[n:2 * n, na:na + ns] = spa[sel]
+            scores[2 * n:, na + ns:] = con[sel]
+            self._accumulate(gt_rels, gt_boxes.astype(float), gt_classes, rels, scores,
+                             boxes.astype(float), classes, obj_scores)
+
+    def _accumulate(self, gt_rels, gt_boxes, gt_classes, rels, scores, boxes, classes, obj_scores):
+        m, n_gt = self.mode, gt_rels.shape[0]
+        assert n_gt != 0
+
+        def run(pred_rels, pscore):
+            return match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, boxes, classes, pscore, obj_scores,
+                                     self.iou_threshold)
+
+        # with graph constraint: one predicate (the arg-max) per row (:221-235)
+        hits_c = run(np.column_stack((rels, scores.argmax(1))), scores.max(1))
+        for k, (r, _) in _recall_at(hits_c, n_gt).items():
+            self.result_dict[f"{m}_recall"][k].append(r)
+        # no graph constraint: the 100 best (row, predicate) entries of obj-score-weighted scores (:351-356)
+        overall = (obj_scores[rels].prod(1))[:, None] * scores
+        flat = np.argsort(-overall.ravel())[:100]
+        ri, ci = np.unravel_index(flat, overall.shape)
+        hits_n = run(np.column_stack((rels[ri], ci)), scores[ri, ci])
+        for k, (r, _) in _recall_at(hits_n, n_gt).items():
+            self.result_dict[f"{m}_recall_nogc"][k].append(r)
+        # semi constraint: arg-max for attention rows, every predicate above 0.5 for the others (:270-288)
+        s_rels, s_sc = [], []
+        for i in range(rels.shape[0]):
+            row = scores[i]
+            if row[0] + row[1] > 0:
+                s_rels.append(np.append(rels[i], row.argmax())); s_sc.append(row.max())
+            elif row[3] + row[4] > 0 or row[9] + row[10] > 0:
+                for kk in np.nonzero(row > 0.5)[0]:
+                    s_rels.append(np.append(rels[i], kk)); s_sc.append(row[kk])
+        hits_s = run(np.array(s_rels), np.array(s_sc))
+        for k, (r, _) in _recall_at(hits_s, n_gt).items():
+            self.result_dict[f"{m}_semi_recall"][k].append(r)
+        # per-predicate recall lists for the two mean-recall variants (:126-148); slot 0 also
+        # receives the all-predicates count, as in the reference
+        for name, hits in (("mean_recall", hits_c), ("ng_mean_recall", hits_n)):
+            for k, (_, got) in _recall_at(hits, n_gt).items():
+                cnt = np.zeros(self.num_rel); hit = np.zeros(self.num_rel)
+                for lab in gt_rels[:, 2]:
+                    cnt[int(lab)] += 1; cnt[0] += 1
+                for g in got:
+                    hit[int(gt_rels[g, 2])] += 1; hit[0] += 1
+                col = self.result_dict[f"{m}_{name}_collect"][k]
+                for p in range(self.num_rel):
+                    if cnt[p] > 0:
+                        col[p].append(float(hit[p] / cnt[p]))
+
+    # ---- reductions / report ---------------------------------------------------------------------
+    def calculate_mean_recall(self):
+        m = self.mode
+        for name in ("mean_recall", "ng_mean_recall"):
+            for k in KS:
+                per = [float(np.mean(v)) if len(v) else 0.0 for v in self.result_dict[f"{m}_{name}_collect"][k]]
+                self.result_dict[f"{m}_{name}_list"][k] = per
+                self.result_dict[f"{m}_{name}"][k] = sum(per) / float(self.num_rel)
+
+    def summary(self):
+        """{metric: {k: value}} with the per-frame lists averaged."""
+        m, out = self.mode, {}
+        for t in ("recall", "recall_nogc", "semi_recall"):
+            out[t] = {k: float(np.mean(v)) if len(v) else float("nan") for k, v in self.result_dict[f"{m}_{t}"].items()}
+        for t in ("mean_recall", "ng_mean_recall"):
+            out[t] = {k: float(v) for k, v in self.result_dict[f"{m}_{t}"].items()}
+        return out
+
+    def print_stats(self, logger=None):
+        s = self.summary()
+        lines = ["======================" + self.mode + "============================"]
+        names = {"recall": ("  R", "Recall(Main)"), "recall_nogc": ("  R", "No Graph Constraint Recall(Main)"),
+                 "semi_recall": ("  R", "Semi Recall"), "mean_recall": (" mR", "Mean Recall"),
+                 "ng_mean_recall": ("ng-mR", "No Graph Constraint Mean Recall")}
+        for t, (tag, title) in names.items():
+            lines.append("SGG eval: " + "".join(f"{tag} @ {k}: {s[t][k]:.4f}; " for k in KS)
+                         + f" for mode={self.mode}, type={title}.")
+        text = "\n".join(lines)
+        (logger.info if logger is not None else print)(text)
+        return text

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Known-answer vectors for the evaluator: runs the REFERENCE `lib/evaluation_recall.py`
+(build container only) on the golden model outputs + seeded synthetic ground truth, and stores the
+recall lists it produces as tests/golden/eval_<case>.json (data only).
+
+The reference's Cython IoU (`lib/fpn/box_intersections_cpu/bbox.pyx`) is compiled out-of-tree into a
+temp dir with `numpy.float = float` (it predates numpy 1.24)."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+
+CASES = {"uniform_16x12": "predcls", "ragged_5": "predcls", "sgdet_ragged": "sgdet"}
+OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
+ATT = [f"att{i}" for i in range(3)]
+SPA = [f"spa{i}" for i in range(6)]
+CON = [f"con{i}" for i in range(17)]
+
+
+def build_bbox():
+    np.float = float  # noqa
+    tmp = tempfile.mkdtemp(prefix="refbbox_")
+    src = os.path.join(REF, "lib/fpn/box_intersections_cpu/bbox.pyx")
+    setup = os.path.join(tmp, "setup.py")
+    with open(setup, "w") as f:
+        f.write("from setuptools import setup, Extension\nfrom Cython.Build import cythonize\nimport numpy\n"
+                f"setup(ext_modules=cythonize(Extension('bbox', [r'{src}'], include_dirs=[numpy.get_include()]),"
+                f" language_level=2, build_dir=r'{tmp}/b'))\n")
+    subprocess.run([sys.executable, setup, "build_ext", "--build-lib", tmp, "--build-temp", tmp + "/t"],
+                   check=True, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, tmp)
+    bbox = importlib.import_module("bbox")
+    import lib  # noqa
+    pk = types.ModuleType("lib.fpn.box_intersections_cpu"); pk.__path__ = []
+    sys.modules[pk.__name__] = pk
+    sys.modules["lib.fpn.box_intersections_cpu.bbox"] = bbox
+    sys.modules["h5py"] = types.ModuleType("h5py")
+
+
+def main():
+    build_bbox()
+    from lib.evaluation_recall import SceneGraphEvaluator as RefEval
+    for case, mode in CASES.items():
+        g = np.load(os.path.join(HERE, f"sttran_{case}.npz"))
+        e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
+                           im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
+        gt = syn.make_gt_annotation(1000 + int(g["entry_seed"]), e)
+        for fr in gt:
+            for o in fr[1:]:
+                for k in ("attention_relationship", "spatial_relationship", "contacting_relationship"):
+                    o[k] = torch.from_numpy(np.asarray(o[k]))
+        pred = {k: torch.from_numpy(e[k]) for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+        for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+            pred[k] = torch.from_numpy(g[k])
+        pred["pred_labels"], pred["pred_scores"] = pred["labels"], pred["scores"]
+        ev = RefEval(mode=mode, AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
+                     AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
+                     iou_threshold=0.5, constraint="with")
+        ev.register_container()
+        ev.evaluate_scene_graph(gt, pred)
+        ev.calculate_mean_recall()
+        out = {}
+        for key, val in ev.result_dict.items():
+            if key.endswith("_collect"):
+                continue
+            out[key] = {str(k): (v if isinstance(v, (int, float)) else [float(x) for x in v]) for k, v in val.items()}
+        with open(os.path.join(HERE, f"eval_{case}.json"), "w") as f:
+            json.dump({"mode": mode, "gt_seed": 1000 + int(g["entry_seed"]), "result_dict": out}, f, indent=0)
+        print(case, {k: round(float(np.mean(v)), 4) for k, v in ev.result_dict[mode + "_recall"].items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""The package's SceneGraphEvaluator against recall values captured from the reference evaluator
+(tests/golden/gen_golden_eval.py).  CPU only; identical numbers are required, not a tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nl_vsgg_amd.lib import synthetic as syn
+from nl_vsgg_amd.lib.evaluation_recall import SceneGraphEvaluator, box_iou_plus1
+
+OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
+ATT = [f"att{i}" for i in range(3)]
+SPA = [f"spa{i}" for i in range(6)]
+CON = [f"con{i}" for i in range(17)]
+
+
+def _run(case, golden_dir, perturb=0.0):
+    ref = json.load(open(os.path.join(golden_dir, f"eval_{case}.json")))
+    g = np.load(os.path.join(golden_dir, f"sttran_{case}.npz"))
+    mode = ref["mode"]
+    e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
+                       im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
+    gt = syn.make_gt_annotation(ref["gt_seed"], e)
+    pred = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+        pred[k] = g[k] + np.float32(perturb)
+    pred["pred_labels"], pred["pred_scores"] = pred["labels"], pred["scores"]
+    ev = SceneGraphEvaluator(mode=mode, AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
+                             AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
+                             iou_threshold=0.5)
+    ev.register_container()
+    ev.evaluate_scene_graph(gt, pred)
+    ev.calculate_mean_recall()
+    return ev, ref["result_dict"], mode
+
+
+@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5", "sgdet_ragged"])
+def test_recall_identical_to_reference(case, golden_dir):
+    ev, ref, mode = _run(case, golden_dir)
+    for t in ("recall", "recall_nogc", "semi_recall"):
+        for k in (10, 20, 50):
+            assert ev.result_dict[f"{mode}_{t}"][k] == ref[f"{mode}_{t}"][str(k)], (t, k)
+    for t in ("mean_recall", "ng_mean_recall"):
+        for k in (10, 20, 50):
+            assert ev.result_dict[f"{mode}_{t}"][k] == pytest.approx(ref[f"{mode}_{t}"][str(k)], abs=1e-12)
+            np.testing.assert_allclose(ev.result_dict[f"{mode}_{t}_list"][k], ref[f"{mode}_{t}_list"][str(k)], atol=1e-12)
+
+
+def test_recall_stable_under_1e3_logit_noise(golden_dir):
+    """Recall@K is what the 1e-3 logit tolerance protects: a uniform 1e-4 shift changes nothing."""
+    a, _, mode = _run("uniform_16x12", golden_dir)
+    b, _, _ = _run("uniform_16x12", golden_dir, perturb=1e-4)
+    assert a.summary()["recall"] == b.summary()["recall"]
+
+
+def test_iou_plus_one_convention():
+    # identical boxes -> 1; touching boxes overlap by the +1 pixel column
+    assert box_iou_plus1([0, 0, 9, 9], np.array([[0, 0, 9, 9]]))[0] == 1.0
+    v = box_iou_plus1([0, 0, 9, 9], np.array([[9, 0, 18, 9], [20, 20, 30, 30]]))
+    assert v[0] == pytest.approx(10.0 / 190.0) and v[1] == 0.0
+
+
+def test_print_stats_runs(golden_dir):
+    ev, _, _ = _run("ragged_5", golden_dir)
+    text = ev.print_stats()
+    assert "R @ 20" in text and "type=Recall(Main)" in text

@@ -181,3 +181,28 @@ def test_linearity_of_heads_full_size(predcls):
         assert (a[k][perm_in] - b[k]).abs().max().item() < 2e-4, k
     for k in OUT_KEYS[1:]:
         assert a[k].min().item() >= 0 and a[k].max().item() <= 1
+
+
+@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5"])
+def test_recall_identical_to_reference_pipeline(case, predcls, golden_dir):
+    """HIP model + this package's evaluator == reference model + reference evaluator, recall list by
+    recall list (BASELINE.json: 'identical PredCls Recall@K')."""
+    import json
+    from nl_vsgg_amd.lib.evaluation_recall import SceneGraphEvaluator
+    ref = json.load(open(os.path.join(golden_dir, f"eval_{case}.json")))
+    g = np.load(os.path.join(golden_dir, f"sttran_{case}.npz"))
+    e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist())
+    gt = syn.make_gt_annotation(ref["gt_seed"], e)
+    pred = predcls(_cuda_entry(e))
+    att = [f"att{i}" for i in range(3)]; spa = [f"spa{i}" for i in range(6)]; con = [f"con{i}" for i in range(17)]
+    ev = SceneGraphEvaluator(mode="predcls", AG_object_classes=CLASSES, AG_all_predicates=att + spa + con,
+                             AG_attention_predicates=att, AG_spatial_predicates=spa, AG_contacting_predicates=con)
+    ev.register_container()
+    ev.evaluate_scene_graph(gt, pred)
+    ev.calculate_mean_recall()
+    for t in ("recall", "recall_nogc", "semi_recall"):
+        for k in (10, 20, 50):
+            assert ev.result_dict[f"predcls_{t}"][k] == ref["result_dict"][f"predcls_{t}"][str(k)], (t, k)
+    for k in (10, 20, 50):
+        assert ev.result_dict["predcls_mean_recall"][k] == pytest.approx(
+            ref["result_dict"]["predcls_mean_recall"][str(k)], abs=1e-12)
