@@ -36,7 +36,17 @@ struct GemmOperand {
   const float* ptr;
   int64_t ld;          // row stride in floats (multiple of 4, 16-byte aligned base)
   const int* rowidx;   // optional gather: logical row r reads physical row rowidx[r]
+  int aux;             // B_UNION: number of pairs P (ld = pair stride K*49)
 };
+
+// B-operand kinds.  B_KMAJOR: rows of W[N][K], K-contiguous (nn.Linear weights, im2col rows).
+// B_UNION: the NCHW union_feat tensor U[P][K][49] read in place -- a 256-column tile is five pairs
+// (245 columns, 95.7 % full); per K-step each pair contributes one contiguous [32][49] slab
+// (6 272 bytes), copied flat into LDS; fragments are read with ds_read_b32 (lanes = consecutive
+// hw: conflict-free) using the same k-permutation as the A side.
+enum { B_KMAJOR = 0, B_UNION = 1 };
+constexpr int kUPairs = 5, kUHW = 49, kUSlab = kBK * kUHW;     // 1568 floats per pair per K-step
+constexpr int kUStageB = kUPairs * kUSlab;                     // 7840 floats
 
 // ---- epilogues: called once per output element as epi(row, col, acc) --------------------
 struct EpiLinear {
@@ -84,16 +94,33 @@ struct EpiConvRelBn {
   }
 };
 
-template <int BM_, int BN_, int WM_, int WN_>
+// union_func1 as GEMM (B_UNION): row = out channel, col = 256*group + j, j < 245 = (pair in group, hw).
+// V already holds the mask-conv branch: V[p][c][hw] += acc + bias[c]   (lib/sttran.py:386).
+struct EpiUnion {
+  float* V; const float* bias; int C; int P;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    const int g = col >> 8, j = col & 255;
+    if (j >= kUPairs * kUHW) return;
+    const int q = j / kUHW, hw = j - q * kUHW, p = g * kUPairs + q;
+    if (p >= P) return;
+    float* dst = V + ((int64_t)p * C + row) * kUHW + hw;
+    *dst += v + bias[row];
+  }
+};
+
+template <int BM_, int BN_, int WM_, int WN_, int BKIND_ = B_KMAJOR>
 struct GemmTile {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BKIND = BKIND_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int AV = BM * 8 / NT, BV = BN * 8 / NT;      // float4 loads per thread per step
-  static constexpr int STAGE = (BM + BN) * kLdsStride;          // floats per LDS stage
+  static constexpr int AV = BM * 8 / NT;                               // float4 loads per thread per step
+  static constexpr int BV = BKIND == B_UNION ? (kUStageB / 4 + NT - 1) / NT : BN * 8 / NT;
+  static constexpr int STAGE_B = BKIND == B_UNION ? kUStageB : BN * kLdsStride;
+  static constexpr int STAGE = BM * kLdsStride + STAGE_B;              // floats per LDS stage
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+  static_assert((BM * 8) % NT == 0, "A staging must divide evenly");
+  static_assert(BKIND == B_UNION ? BN == 256 : (BN * 8) % NT == 0, "B staging must divide evenly");
 };
 
 // XCD-aware, bijective remap of a linear block id: ids that are equal mod 8 share an XCD, so
@@ -125,6 +152,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
                float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
+  constexpr bool UNION = T::BKIND == B_UNION;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -132,7 +160,18 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
   const int fr = lane & 31, fh = lane >> 5;
   const int kq4 = (tid & 7) * 4;
   const int a_off = (wm * (BM / T::WM) + fr) * kLdsStride + fh * 4;
-  const int b_off = (BM + wn * (BN / T::WN) + fr) * kLdsStride + fh * 4;
+  // B fragment base offsets per 32-column MFMA tile of this wave
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / T::WN) + j * 32 + fr;
+    if constexpr (UNION) {
+      const int q = col / kUHW, hw = col - q * kUHW;
+      b_off[j] = BM * kLdsStride + (col < kUPairs * kUHW ? q * kUSlab + hw : 0) + fh * 4 * kUHW;
+    } else {
+      b_off[j] = (BM + col) * kLdsStride + fh * 4;
+    }
+  }
 
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);      // neighbouring ranges (shared weight panels) on one XCD
@@ -144,58 +183,78 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     const int ks0 = (int)(it - (int64_t)tile * ksteps);
     const int ks1 = (int)min((int64_t)ksteps, ks0 + (rg.end - it));
     const int nsteps = ks1 - ks0;
-    const int m0 = (tile % tiles_m) * BM;          // consecutive tiles share the weight panel
+    const int m0 = (tile % tiles_m) * BM;          // consecutive tiles share the B panel
     const int n0 = (tile / tiles_m) * BN;
     const int k_begin = ks0 * kBK;
     const int k_end = min(K, ks1 * kBK);
 
     // Staging slots.  Rows past M/N and the K tail are loaded from a valid address (row 0 / k 0) and
-    // zeroed by a select, so the loads stay unconditional (no exec-mask branches in the loop).
+    // zeroed by a select at the LDS write, so the loads stay unconditional (no exec-mask branches in
+    // the loop) and the wait for them sits behind the MFMAs of the current step.
     const float* pa[AV]; const float* pb[BV];
     bool va[AV], vb[BV];
+    int sb[BV];                                    // LDS float offset of each B piece
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + (tid >> 3) + i * (NT >> 3);
       va[i] = g < M;
-      pa[i] = A.ptr + (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld;
+      pa[i] = A.ptr + (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + kq4;
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      const int g = n0 + (tid >> 3) + i * (NT >> 3);
-      vb[i] = g < N;
-      pb[i] = B.ptr + (int64_t)(vb[i] ? (B.rowidx ? B.rowidx[g] : g) : 0) * B.ld;
+      if constexpr (UNION) {
+        const int idx = tid + i * NT;              // float4 index inside the 5-pair stage
+        const int q = idx / (kUSlab / 4), f = idx - q * (kUSlab / 4);
+        const int p = (n0 / BN) * kUPairs + q;
+        vb[i] = idx < kUStageB / 4 && p < B.aux;
+        sb[i] = idx < kUStageB / 4 ? BM * kLdsStride + q * kUSlab + f * 4 : -1;
+        pb[i] = B.ptr + (int64_t)(vb[i] ? p : 0) * B.ld + f * 4;
+      } else {
+        const int g = n0 + (tid >> 3) + i * (NT >> 3);
+        vb[i] = g < N;
+        sb[i] = (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4;
+        pb[i] = B.ptr + (int64_t)(vb[i] ? (B.rowidx ? B.rowidx[g] : g) : 0) * B.ld + kq4;
+      }
     }
     f32x4 ra[AV], rb[BV];
-    bool kok_loaded = true;
+    bool kok_a = true, kok_b = true;               // validity of the K range currently held in ra / rb
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load_tile = [&](int k0) {
-      kok_loaded = (k0 + kq4) < k_end;          // K is a multiple of 4: a float4 is all-in or all-out
-      const int ko = kok_loaded ? k0 + kq4 : 0;
-#pragma unroll
-      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + ko);
-#pragma unroll
-      for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + ko);
+    int ka = 0, kb_src = 0;                        // element offsets of the next load (A side, B side)
+    auto set_k = [&](int k0) {
+      // K-major rows: a float4 is all-in or all-out of [k_begin,k_end) because K % 4 == 0.
+      // Union slabs need K % 32 == 0 (checked by the launcher): a K-step is never partial.
+      kok_a = (k0 + kq4) < k_end;
+      kok_b = UNION ? k0 < k_end : kok_a;
+      ka = kok_a ? k0 : 0;
+      kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : ka;
     };
-    // the zero-select happens here, at the LDS write, so that the wait for the global loads sits
-    // after the MFMAs of the current step and not right behind the load issue
-    auto store_tile = [&](float* stage) {
-#pragma unroll
-      for (int i = 0; i < AV; ++i)
-        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) =
-            (va[i] && kok_loaded) ? ra[i] : zero4;
-#pragma unroll
-      for (int i = 0; i < BV; ++i)
-        *reinterpret_cast<f32x4*>(stage + (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) =
-            (vb[i] && kok_loaded) ? rb[i] : zero4;
+    auto load_piece = [&](int n) {
+      if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
+      else rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);
     };
-    // fragment group kb of a stage: k = kb*8 + 4*(lane>>5) + {0..3} for A rows and W rows alike
+    auto store_piece = [&](int n, float* stage) {
+      if (n < AV) {
+        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
+            (va[n] && kok_a) ? ra[n] : zero4;
+      } else {
+        const int i = n - AV;
+        if (!UNION || sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
+      }
+    };
+    // fragment group kb of a stage: k = kb*8 + 4*(lane>>5) + {0..3} for A rows and B alike
     auto read_frags = [&](const float* stage, int kb, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         fa[i] = *reinterpret_cast<const f32x4*>(stage + a_off + i * 32 * kLdsStride + kb * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const f32x4*>(stage + b_off + j * 32 * kLdsStride + kb * 8);
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (UNION) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[j][e] = stage[b_off[j] + (kb * 8 + e) * kUHW];
+        } else {
+          fb[j] = *reinterpret_cast<const f32x4*>(stage + b_off[j] + kb * 8);
+        }
+      }
     };
 
     f32x16 acc[TM][TN];
@@ -215,23 +274,28 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
-    load_tile(k_begin);
-    store_tile(smem);
+    set_k(k_begin);
+#pragma unroll
+    for (int n = 0; n < AV + BV; ++n) load_piece(n);
+#pragma unroll
+    for (int n = 0; n < AV + BV; ++n) store_piece(n, smem);
     __syncthreads();
     if constexpr (PIPE == 0) {
-      // plain loop: fragments of group kb are read right before its MFMAs (the compiler's own
-      // lgkmcnt ladder), one barrier per K-step
+      // plain loop (kept for A/B runs of tools/gemm_bench.py): fragments of group kb are read right
+      // before its MFMAs, staging clustered before/after the MFMAs, one barrier per K-step
       f32x4 fa[TM], fb[TN];
       for (int t = 0; t < nsteps; ++t) {
         const float* cur = smem + (t & 1) * T::STAGE;
-        const bool more = t + 1 < nsteps;
-        if (more) load_tile(k_begin + (t + 1) * kBK);
+        set_k(k_begin + (t + 1) * kBK);
+#pragma unroll
+        for (int n = 0; n < AV + BV; ++n) load_piece(n);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           read_frags(cur, kb, fa, fb);
           mma(fa, fb);
         }
-        if (more) store_tile(smem + ((t + 1) & 1) * T::STAGE);
+#pragma unroll
+        for (int n = 0; n < AV + BV; ++n) store_piece(n, smem + ((t + 1) & 1) * T::STAGE);
         __syncthreads();
       }
     } else {
@@ -242,14 +306,15 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       // cycles but the issue port for 8): group 0 carries the global loads of the next tile, group 2
       // carries their select + ds_write, so neither costs issue time of its own.  Loads and stores
       // run on the last step too (from a clamped address, into the idle buffer): no branches.
+      // sched_barrier / sched_group_barrier pin this order: left alone, hipcc sinks every load to
+      // just before its use, which exposes the full memory latency each step.
+      constexpr int NP = AV + BV, NM = 4 * TM * TN;
       f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
       read_frags(smem, 0, fa0, fb0);
       for (int t = 0; t < nsteps; ++t) {
         const float* cur = smem + (t & 1) * T::STAGE;
         float* nxt = smem + ((t + 1) & 1) * T::STAGE;
-        const int k0 = k_begin + (t + 1) * kBK;
-        kok_loaded = (k0 + kq4) < k_end;
-        const int ko = kok_loaded ? k0 + kq4 : 0;
+        set_k(k_begin + (t + 1) * kBK);
         read_frags(cur, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -261,18 +326,14 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ko);
-                else if (n < AV + BV) rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + ko);
+                if (n < NP) load_piece(n);
                 ++n;
               }
 #pragma unroll
-          for (; n < AV + BV; ++n) {       // tiles with fewer MFMAs than loads
-            if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ko);
-            else rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + ko);
-          }
+          for (; n < NP; ++n) load_piece(n);       // tiles with fewer MFMAs per group than pieces
           // one global load per MFMA gap (sched_group_barrier masks: 0x8 MFMA, 0x20 VMEM read)
 #pragma unroll
-          for (int q = 0; q < AV + BV && q < 4 * TM * TN; ++q) {
+          for (int q = 0; q < NP && q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
           }
@@ -291,26 +352,14 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < AV)
-                  *reinterpret_cast<f32x4*>(nxt + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
-                      (va[n] && kok_loaded) ? ra[n] : zero4;
-                else if (n < AV + BV)
-                  *reinterpret_cast<f32x4*>(nxt + (BM + (tid >> 3) + (n - AV) * (NT >> 3)) * kLdsStride + kq4) =
-                      (vb[n - AV] && kok_loaded) ? rb[n - AV] : zero4;
+                if (n < NP) store_piece(n, nxt);
                 ++n;
               }
 #pragma unroll
-          for (; n < AV + BV; ++n) {
-            if (n < AV)
-              *reinterpret_cast<f32x4*>(nxt + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
-                  (va[n] && kok_loaded) ? ra[n] : zero4;
-            else
-              *reinterpret_cast<f32x4*>(nxt + (BM + (tid >> 3) + (n - AV) * (NT >> 3)) * kLdsStride + kq4) =
-                  (vb[n - AV] && kok_loaded) ? rb[n - AV] : zero4;
-          }
+          for (; n < NP; ++n) store_piece(n, nxt);
           // one select + ds_write per MFMA gap (0x2 VALU, 0x200 DS write)
 #pragma unroll
-          for (int q = 0; q < AV + BV && q < 4 * TM * TN; ++q) {
+          for (int q = 0; q < NP && q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x2, 4, 1);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);

@@ -8,7 +8,8 @@
 namespace sttran {
 
 // ---- GEMM ------------------------------------------------------------------------------
-enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_COUNT = 5 };
+enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_UNION = 5,
+       TILE_COUNT = 6 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
@@ -35,7 +36,7 @@ hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float
 hipError_t launch_im2col3x3(hipStream_t s, const float* c2, float* cols, int P);
 // union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]   (V already holds the mask-conv branch)
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
-                             int P, int K);
+                             int P, int K, float* slab);
 
 // ---- transformer pieces ----------------------------------------------------------------------
 hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,

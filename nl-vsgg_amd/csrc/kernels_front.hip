@@ -160,159 +160,6 @@ hipError_t launch_im2col3x3(hipStream_t s, const float* c2, float* cols, int P) 
 }
 
 // ------------------------------------------------------------------------------------------
-// union_conv: `self.union_func1(entry['union_feat'])` (lib/sttran.py:336,386), a 1x1 conv =
-//     V[p][c][hw] += bias[c] + sum_k W[c][k] * U[p][k][hw]          c<256, k<K(2048), hw<49
-// as an MFMA GEMM with M = out channels, N = (pair, hw).  Five pairs (245 columns) fill a
-// 256-column tile to 95.7 %.  U is the largest tensor on the path (401 KB per pair): each
-// (pair, K-step) slab [32][49] is one contiguous 6272-byte run, copied flat with dwordx4 loads
-// into LDS, from which the B fragments are read with conflict-free ds_read_b32 (lanes =
-// consecutive hw).  The A operand (W, K-contiguous) uses the same staged layout and the same
-// k-permutation as gemm_f32_mfma.h, so MFMA j of a group pairs A[.][kb+4h+j] with U[kb+4h+j][.].
-// ------------------------------------------------------------------------------------------
-constexpr int kUPairs = 5, kUHW = 49, kUSlab = kBK * kUHW;          // 1568 floats per pair per step
-constexpr int kUStageB = kUPairs * kUSlab;                          // 7840 floats
-
-template <int BM, int WM, int WN>
-__global__ void __launch_bounds__(512)
-union_conv_kernel(const float* __restrict__ U, const float* __restrict__ W, const float* __restrict__ bias,
-                  float* __restrict__ V, int P, int K, int C) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = 512, TM = BM / WM / 32, TN = 256 / WN / 32, AV = BM * 8 / NT;
-  constexpr int STAGE = BM * kLdsStride + kUStageB;
-  constexpr int BVU = (kUStageB / 4 + NT - 1) / NT;   // 4
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int nmb = C / BM;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int pg = logical / nmb, mb = logical % nmb;
-  const int p0 = pg * kUPairs, m0 = mb * BM;
-  const int npairs = min(kUPairs, P - p0);
-
-  const int kq4 = (tid & 7) * 4;
-  const float* pa[AV > 0 ? AV : 1];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) pa[i] = W + (int64_t)(m0 + (tid >> 3) + i * (NT >> 3)) * K + kq4;
-  const float* pu[BVU]; int su[BVU];
-#pragma unroll
-  for (int i = 0; i < BVU; ++i) {
-    const int idx = tid + i * NT;                 // float4 index in the 5-pair stage
-    const int q = idx / (kUSlab / 4), f = idx - q * (kUSlab / 4);
-    const bool ok = idx < kUStageB / 4 && q < npairs;
-    pu[i] = ok ? U + ((int64_t)(p0 + q) * K) * kUHW + f * 4 : nullptr;
-    su[i] = idx < kUStageB / 4 ? q * kUSlab + f * 4 : -1;
-  }
-  f32x4 ra[AV > 0 ? AV : 1], ru[BVU];
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
-#pragma unroll
-    for (int i = 0; i < BVU; ++i)
-      ru[i] = pu[i] ? *reinterpret_cast<const f32x4*>(pu[i] + (int64_t)k0 * kUHW) : f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto store_tile = [&](float* st) {
-#pragma unroll
-    for (int i = 0; i < AV; ++i)
-      *reinterpret_cast<f32x4*>(st + ((tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BVU; ++i)
-      if (su[i] >= 0) *reinterpret_cast<f32x4*>(st + BM * kLdsStride + su[i]) = ru[i];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5;
-  const int a_off = (wm * (BM / WM) + fr) * kLdsStride + fh * 4;
-  int b_off[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * (256 / WN) + j * 32 + fr;
-    const int q = col / kUHW, hw = col - q * kUHW;
-    b_off[j] = BM * kLdsStride + (col < kUPairs * kUHW ? q * kUSlab + hw : 0) + fh * 4 * kUHW;
-  }
-
-  const int nsteps = K / kBK;
-  load_tile(0);
-  store_tile(smem);
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    const float* cur = smem + (t & 1) * STAGE;
-    if (t + 1 < nsteps) load_tile((t + 1) * kBK);
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      f32x4 fa[TM];
-      float fb[TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(cur + a_off + i * 32 * kLdsStride + kb * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) fb[j][e] = cur[b_off[j] + (kb * 8 + e) * kUHW];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nsteps) store_tile(smem + ((t + 1) & 1) * STAGE);
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * (256 / WN) + j * 32 + fr;
-    const int q = col / kUHW, hw = col - q * kUHW;
-    if (col >= kUPairs * kUHW || q >= npairs) continue;
-    float* vp = V + ((int64_t)(p0 + q) * C) * kUHW + hw;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * fh;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int c = rbase + (e & 3) + 8 * (e >> 2);
-        vp[(int64_t)c * kUHW] += acc[i][j][e] + bias[c];
-      }
-    }
-  }
-}
-
-template <int BM, int WM, int WN>
-static hipError_t launch_union_t(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
-                                 int P, int K) {
-  constexpr int STAGE = BM * kLdsStride + kUStageB;
-  const int lds = 2 * STAGE * 4;
-  static bool attr = false;
-  auto kern = union_conv_kernel<BM, WM, WN>;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  const int groups = (P + kUPairs - 1) / kUPairs;
-  hipLaunchKernelGGL(kern, dim3(groups * (256 / BM)), dim3(512), lds, s, U, W, bias, V, P, K, 256);
-  return hipGetLastError();
-}
-
-hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V, int P,
-                             int K) {
-  if (K % kBK != 0) return hipErrorInvalidValue;
-  const int groups = (P + kUPairs - 1) / kUPairs;
-  // few pair groups: split the 256 output channels over more workgroups to fill the 256 CUs
-  if (groups >= 192) return launch_union_t<256, 4, 2>(s, U, W, bias, V, P, K);
-  if (groups >= 96) return launch_union_t<128, 2, 4>(s, U, W, bias, V, P, K);
-  return launch_union_t<64, 1, 8>(s, U, W, bias, V, P, K);
-}
-
-// ------------------------------------------------------------------------------------------
 // objcls_prep: ObjectClassifier input of the sgdet+wks branch (lib/sttran.py:174-176):
 //   z[b] = [ features[b] | distribution[b] @ obj_embed.weight | ReLU(Linear(BN1d(center_size(box)))) ]
 // center_size (lib/fpn/box_utils.py:51-63): wh = xy2 - xy1 + 1, c = xy1 + 0.5 wh.

@@ -11,13 +11,15 @@ using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
+using TUnion = GemmTile<128, 256, 2, 4, B_UNION>;   // 8 waves, wave tile 64x64, B = NCHW union_feat slabs
 
 struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // eff = fraction of the fp32-MFMA peak the tile's main loop sustains on a large square problem
 // (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
 // (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 128, 0.85f, 1}, {128, 128, 0.83f, 2}, {64, 64, 0.74f, 4}, {128, 64, 0.77f, 2}};
+    {0, 0, 0.f, 0}, {256, 128, 0.85f, 1}, {128, 128, 0.83f, 2}, {64, 64, 0.74f, 4}, {128, 64, 0.77f, 2},
+    {128, 256, 0.80f, 1}};   // last: TILE_UNION (never chosen by plan_gemm)
 
 static int num_cus() {
   static int n = 0;
@@ -41,7 +43,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   GemmPlan best{TILE_128x128, 1};
   double best_t = 1e300;
   const int64_t ksteps = (K + kBK - 1) / kBK;
-  for (int t = 1; t < TILE_COUNT; ++t) {
+  for (int t = 1; t < TILE_UNION; ++t) {
     if (force_tile && t != force_tile) continue;
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
@@ -135,6 +137,18 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
   return gemm_generic<EpiHeads>(s, A, B, M, N, K, epi, plan, slab);
 }
+// union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K
+// over (tile, K-step) like every other GEMM
+hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V, int P,
+                             int K, float* slab) {
+  if (K % kBK != 0 || P <= 0) return hipErrorInvalidValue;
+  const int groups = (P + kUPairs - 1) / kUPairs;
+  GemmOperand A{W, (int64_t)K, nullptr, 0};
+  GemmOperand B{U, (int64_t)K * kUHW, nullptr, P};
+  EpiUnion epi{V, bias, 256, P};
+  return launch_tile<TUnion, EpiUnion>(s, TILE_UNION, A, B, 256, groups * 256, K, slab, epi);
+}
+
 hipError_t gemm_conv(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                      const EpiConvRelBn& epi, GemmPlan plan, float* slab) {
   return gemm_generic<EpiConvRelBn>(s, A, B, M, N, K, epi, plan, slab);

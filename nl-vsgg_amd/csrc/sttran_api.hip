@@ -204,7 +204,7 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     HIPCK(hipStreamSynchronize(s));
     HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
   }
-  GemmOperand B{Wt, (int64_t)K, nullptr};
+  GemmOperand B{Wt, (int64_t)K, nullptr, 0};
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
   HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>()));
   return STTRAN_OK;
@@ -437,7 +437,7 @@ int sttran_finalize_weights(SttranHandle* h) {
   //   (g + pos) Wqk^T + b = g Wqk^T + (pos Wqk^T) + b      (lib/transformer.py:51, pos is one of 2 rows)
   for (int i = 0; i < c.dec_layers; ++i) {
     const std::string pre = "glocal_transformer.global_attention.layers." + std::to_string(i) + ".multihead2";
-    GemmOperand A{W(h, "glocal_transformer.position_embedding.weight"), D, nullptr};
+    GemmOperand A{W(h, "glocal_transformer.position_embedding.weight"), D, nullptr, 0};
     EpiLinear e = epi_plain(h->dec[i].posbias, 2 * D, nullptr);
     if ((rc = run_linear(h, nullptr, A, W(h, pre + ".in_proj_weight"), 2, (int)(2 * D), (int)D, e))) return rc;
   }
@@ -628,7 +628,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   }
   {
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
-    HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD));
+    HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+                            h->slab.as<float>()));
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
                        epi_plain(X0 + 1024, D, W(h, "vr_fc.bias"))))) return rc;
