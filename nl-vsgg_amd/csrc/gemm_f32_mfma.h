@@ -52,20 +52,22 @@ constexpr int kUStageB = kUPairs * kUSlab;                     // 7840 floats
 struct EpiLinear {
   float* C; int64_t ldc;
   const float* bias;        // [N] or null
-  const float* rowbias;     // [2][rb_ld] extra bias selected by rowslot[row] for col < rb_cols
+  const float* rowbias;     // [2][rb_ld] extra bias selected by rowslot[out row] for col < rb_cols
   const uint8_t* rowslot;
   int rb_cols; int rb_ld;
   const float* scale;       // per-col affine applied after bias (BatchNorm eval), or null
   const float* shift;
   const float* res; int64_t ldres; const int* res_rowidx;   // residual add, optional gather
   int relu;
+  const int* out_rowidx;    // optional scatter: GEMM row r is written to C row out_rowidx[r]
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    const int orow = out_rowidx ? out_rowidx[row] : row;
     if (bias) v += bias[col];
-    if (rowbias && col < rb_cols) v += rowbias[(int)rowslot[row] * rb_ld + col];
+    if (rowbias && col < rb_cols) v += rowbias[(int)rowslot[orow] * rb_ld + col];
     if (scale) v = v * scale[col] + shift[col];
     if (relu) v = fmaxf(v, 0.f);
     if (res) v += res[(int64_t)(res_rowidx ? res_rowidx[row] : row) * ldres + col];
-    C[(int64_t)row * ldc + col] = v;
+    C[(int64_t)orow * ldc + col] = v;
   }
 };
 

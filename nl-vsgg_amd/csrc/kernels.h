@@ -41,8 +41,9 @@ hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, cons
 // ---- transformer pieces ----------------------------------------------------------------------
 hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
                             int64_t rows, int dim);
+// q_begin (optional, per sequence): compute only query rows [q_begin, len)
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
-                            int num_seq, int max_len, float* out, int dim, int nhead);
+                            const int* q_begin, int num_seq, int max_len, float* out, int dim, int nhead);
 constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel accepts
 hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
                               int dim);

@@ -1,5 +1,7 @@
 // kernels_attn.hip -- attention core, LayerNorm and row gather of the spatial encoder / temporal
 // decoder (lib/transformer.py:20-30, 49-58; nn.MultiheadAttention semantics).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace sttran {
@@ -134,23 +136,212 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
   }
 }
 
-hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
-                            int max_len, float* out, int dim, int nhead) {
+// ------------------------------------------------------------------------------------------
+// Short-sequence attention (every sequence <= kAttnShortMax keys -- always the case for per-frame /
+// two-frame-window sequences of a few dozen boxes): ONE workgroup per (sequence, head) stages K and V
+// once for all of the sequence's queries, on 16x16x4 MFMA tiles (16-row granularity: a 70-token
+// window pads to 80, not 96).
+//   phase 1  S = Q K^T : head_dim is processed in two 128-wide chunks so that Q and K chunks
+//            ([L16][132] each, row stride 132 dwords = conflict-free ds_read_b128) fit LDS together;
+//            each wave owns up to 7 score tiles whose accumulators persist across the chunks
+//   softmax  rows of S in LDS, wavefront shuffles, P written back normalised
+//   phase 2  O = P V   : V [L16][260] overwrites the Q/K region; wave w owns output columns
+//            [64w, 64w+64) for all query tiles (P rows as A operand via ds_read_b128, V as B operand via
+//            conflict-free ds_read_b32)
+// q_begin (optional) = first query row of each sequence to compute: the last decoder layer only
+// needs the rows the 'latter' scatter reads (lib/transformer.py:179-185).
+// ------------------------------------------------------------------------------------------
+constexpr int kAttnShortMax = 80;
+constexpr int kChunk = 128, kCStride = kChunk + 4;      // 132 dwords: (132/4) odd -> distinct LDS slots
+constexpr int kShortTilesPerWave = 7;                   // ceil(5*5 / 4)
+
+template <int NCOLS_PAD>
+__device__ __forceinline__ void stage_rows(float* dst, int dstride, const float* __restrict__ src, int64_t ld,
+                                           int nrows_pad, int nrows_valid, int col0, int ncols_valid, float scale,
+                                           int tid) {
+  // dst[r][c] = scale * src[r][col0 + c] for r < nrows_valid, col0 + c < ncols_valid; zero elsewhere
+  // (c < NCOLS_PAD).  float2 granules (rows are 8-byte aligned: head_dim*4 = 968 bytes); 256 threads;
+  // eight independent loads in flight per thread before the first LDS write.
+  constexpr int HALF = NCOLS_PAD / 2, U = 8;
+  const int total = nrows_pad * HALF;
+  for (int i0 = tid; i0 < total; i0 += 256 * U) {
+    f32x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
+      v[u] = f32x2{0.f, 0.f};
+      if (i < total && r < nrows_valid && col0 + c2 < ncols_valid)
+        v[u] = *reinterpret_cast<const f32x2*>(src + (int64_t)r * ld + col0 + c2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
+      if (i < total) *reinterpret_cast<f32x2*>(dst + r * dstride + c2) = f32x2{v[u][0] * scale, v[u][1] * scale};
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
+                       const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
+                       int dim, int hd, float scale, int l16max) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int s = blockIdx.y, h = blockIdx.x;
+  const int L = seq_len[s];
+  if (L <= 0) return;
+  const int qb = q_begin ? q_begin[s] : 0;
+  const int Lq = L - qb;
+  if (Lq <= 0) return;
+  const int base = seq_off[s];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int Lk16 = (L + 15) & ~15, Lq16 = (Lq + 15) & ~15;
+  const int nq = Lq16 >> 4, nk = Lk16 >> 4, ntiles = nq * nk;
+  const int region = max(2 * l16max * kCStride, l16max * kQStride);
+  float* Qc = smem;                          // [Lq16][132]
+  float* Kc = smem + l16max * kCStride;      // [Lk16][132]
+  float* Vs = smem;                          // [Lk16][260]   (phase 2, overwrites Qc/Kc)
+  float* Ps = smem + region;                 // [Lq16][Lk16 + 4]
+  const int ps = Lk16 + 4;
+  const int64_t ld = 3 * (int64_t)dim;
+  const float* qp = qkv + (int64_t)base * ld + h * hd;
+
+  // ---- phase 1 --------------------------------------------------------------------------------
+  f32x4 acc[kShortTilesPerWave];
+#pragma unroll
+  for (int t = 0; t < kShortTilesPerWave; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < kHdPad; c0 += kChunk) {
+    if (c0) __syncthreads();
+    stage_rows<kChunk>(Qc, kCStride, qp + (int64_t)qb * ld, ld, Lq16, Lq, c0, hd, scale, tid);
+    stage_rows<kChunk>(Kc, kCStride, qp + dim, ld, Lk16, L, c0, hd, 1.f, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kShortTilesPerWave; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < ntiles) {
+        const int qi = tile / nk, kj = tile - qi * nk;
+        const float* ar = Qc + (qi * 16 + l15) * kCStride + 4 * g;
+        const float* br = Kc + (kj * 16 + l15) * kCStride + 4 * g;
+        f32x4 c0a = acc[t], c1a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < kChunk / 16; ++kb) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(ar + kb * 16);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(br + kb * 16);
+          c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0a, 0, 0, 0);
+          c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1a, 0, 0, 0);
+          c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0a, 0, 0, 0);
+          c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1a, 0, 0, 0);
+        }
+        acc[t] = c0a + c1a;
+      }
+    }
+  }
+  // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
+#pragma unroll
+  for (int t = 0; t < kShortTilesPerWave; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile < ntiles) {
+      const int qi = tile / nk, kj = tile - qi * nk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kj * 16 + l15] = acc[t][e];
+    }
+  }
+  __syncthreads();
+
+  // ---- V into the (now free) Q/K region, overlapped with the softmax of other waves' rows -------
+  stage_rows<kHdPad>(Vs, kQStride, qp + 2 * dim, ld, Lk16, L, 0, hd, 1.f, tid);
+  for (int r = wave; r < Lq16; r += 4) {
+    float* pr = Ps + r * ps;
+    float m = -INFINITY;
+    for (int c = lane; c < L; c += 64) m = fmaxf(m, pr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float e0 = (lane < L) ? expf(pr[lane] - m) : 0.f;
+    float e1 = (lane + 64 < L) ? expf(pr[lane + 64] - m) : 0.f;
+    float sum = e0 + e1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float ri = 1.f / sum;
+    if (lane < Lk16) pr[lane] = e0 * ri;
+    if (lane + 64 < Lk16) pr[lane + 64] = e1 * ri;
+  }
+  __syncthreads();
+
+  // ---- phase 2: O[q][d] = sum_key P[q][key] V[key][d]; wave owns d in [64w, 64w+64) -------------
+  constexpr int kMaxQ = kAttnShortMax / 16;      // 5 query tiles
+  f32x4 o[kMaxQ][4];
+#pragma unroll
+  for (int qi = 0; qi < kMaxQ; ++qi)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nk; ++kb) {
+    float bv[4][4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[dt][e] = Vs[(kb * 16 + 4 * g + e) * kQStride + wave * 64 + dt * 16 + l15];
+#pragma unroll
+    for (int qi = 0; qi < kMaxQ; ++qi) {
+      if (qi < nq) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + (qi * 16 + l15) * ps + kb * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv[dt][e], o[qi][dt], 0, 0, 0);
+      }
+    }
+  }
+  float* op = out + (int64_t)(base + qb) * dim + h * hd;
+#pragma unroll
+  for (int qi = 0; qi < kMaxQ; ++qi) {
+    if (qi < nq) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = wave * 64 + dt * 16 + l15;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = qi * 16 + 4 * g + e;
+          if (q < Lq && d < hd) op[(int64_t)q * dim + d] = o[qi][dt][e];
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
+                            const int* q_begin, int num_seq, int max_len, float* out, int dim, int nhead) {
   if (num_seq <= 0 || max_len <= 0) return hipSuccess;
   const int hd = dim / nhead;
   if (hd > kHdPad - 2 || (hd & 1) || max_len > kAttnMaxKeys) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (max_len <= kAttnShortMax) {
+    const int l16 = (max_len + 15) & ~15;
+    const int region = std::max(2 * l16 * kCStride, l16 * kQStride);
+    const int lds = (region + l16 * (l16 + 4)) * 4;
+    static int attr_max = 0;
+    if (lds > attr_max) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_short_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return e;
+      attr_max = lds;
+    }
+    hipLaunchKernelGGL(attention_short_kernel, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len,
+                       q_begin, out, dim, hd, scale, l16);
+    return hipGetLastError();
+  }
+  if (q_begin) return hipErrorInvalidValue;     // the long-sequence kernel computes every query row
   const int skp = (max_len + 31) / 32 * 32;
   const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
-  static int attr_max = 0;
-  if (lds > attr_max) {
+  static int attr_max_long = 0;
+  if (lds > attr_max_long) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_max = lds;
+    attr_max_long = lds;
   }
   dim3 grid((max_len + 31) / 32, nhead, num_seq);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, dim, hd,
-                     1.0f / sqrtf((float)hd), skp);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, dim, hd, scale, skp);
   return hipGetLastError();
 }
 

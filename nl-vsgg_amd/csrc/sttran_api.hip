@@ -43,9 +43,9 @@ struct DevBuf {
 
 struct ProfEvent { hipEvent_t a, b; int cls; };
 
-// worst case of build_layout(): 2P (encoder off/len) + 4P (window off/len) + 2P (dec_src) + P (out_src)
-// + P/2 (slots) int32 words
-constexpr int64_t kIdxIntsPerPair = 12;
+// worst case of build_layout(): 2P (encoder off/len) + 6P (window off/len/q_begin) + 2P (dec_src) +
+// P (out_src) + P (need_idx) + P/2 (slots) int32 words
+constexpr int64_t kIdxIntsPerPair = 16;
 
 struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
 
@@ -77,8 +77,9 @@ struct SttranHandle {
   // layout of the current index buffer
   struct Layout {
     int n_enc_seq = 0, max_enc = 0, n_dec_seq = 0, max_dec = 0;
-    int64_t n_dec_tok = 0;
+    int64_t n_dec_tok = 0, n_need = 0;
     size_t o_enc_off = 0, o_enc_len = 0, o_dec_off = 0, o_dec_len = 0, o_dec_src = 0, o_out_src = 0, o_slot = 0;
+    size_t o_need = 0, o_qbegin = 0;
     size_t total_ints = 0;
   } lay;
   // profiling
@@ -256,7 +257,7 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
   const int T = (int)counts.size();
   std::vector<int64_t> off(T + 1, 0);
   for (int t = 0; t < T; ++t) off[t + 1] = off[t] + counts[t];
-  std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P);
+  std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P), need, qbegin;
   std::vector<uint8_t> slot;
   L = SttranHandle::Layout();
   for (int t = 0; t < T; ++t)
@@ -273,19 +274,28 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
       dec_len.push_back(n0 + n1);
       L.max_dec = std::max(L.max_dec, n0 + n1);
       for (int i = 0; i < n0 + n1; ++i) { dec_src.push_back((int32_t)(off[j] + i)); slot.push_back(i < n0 ? 0 : 1); }
-      if (j == fs) for (int i = 0; i < n0; ++i) out_src[off[j] + i] = (int32_t)(P + doff + i);
-      for (int i = 0; i < n1; ++i) out_src[off[j + 1] + i] = (int32_t)(P + doff + n0 + i);
+      // rows of this window the 'latter' scatter reads (lib/transformer.py:179-185): the first window
+      // of a clip gives both frames, every other window only its second frame.  Only those rows of the
+      // LAST decoder layer are ever consumed, so that layer computes just them (need / q_begin).
+      const int qb = (j == fs) ? 0 : n0;
+      qbegin.push_back(qb);
+      for (int i = qb; i < n0 + n1; ++i) {
+        out_src[off[j] + i] = (int32_t)(P + need.size());
+        need.push_back(doff + i);
+      }
     }
     fs = fe;
   }
   L.n_enc_seq = (int)enc_off.size();
   L.n_dec_seq = (int)dec_off.size();
   L.n_dec_tok = (int64_t)dec_src.size();
+  L.n_need = (int64_t)need.size();
   buf.clear();
   auto put = [&](const std::vector<int32_t>& v) { size_t o = buf.size(); buf.insert(buf.end(), v.begin(), v.end()); return o; };
   L.o_enc_off = put(enc_off); L.o_enc_len = put(enc_len);
   L.o_dec_off = put(dec_off); L.o_dec_len = put(dec_len);
   L.o_dec_src = put(dec_src); L.o_out_src = put(out_src);
+  L.o_need = put(need); L.o_qbegin = put(qbegin);
   L.o_slot = buf.size();
   buf.resize(buf.size() + (slot.size() + 3) / 4, 0);
   if (!slot.empty()) memcpy(buf.data() + L.o_slot, slot.data(), slot.size());
@@ -571,6 +581,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   const int* dec_off = ib + L.o_dec_off; const int* dec_len = ib + L.o_dec_len;
   const int* dec_src = ib + L.o_dec_src; const int* out_src = ib + L.o_out_src;
   const uint8_t* slot = reinterpret_cast<const uint8_t*>(ib + L.o_slot);
+  const int* need = ib + L.o_need; const int* qbegin = ib + L.o_qbegin;
   int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
   int* obj_idx = subj_idx + h->capP;
 
@@ -645,7 +656,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                          epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
     {
       ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * P * L.max_enc * D, 4.0 * P * 4 * D);
-      HIPCK(launch_attention(s, QKV, enc_off, enc_len, L.n_enc_seq, L.max_enc, ATT, D, c.nhead));
+      HIPCK(launch_attention(s, QKV, enc_off, enc_len, nullptr, L.n_enc_seq, L.max_enc, ATT, D, c.nhead));
     }
     EpiLinear eo = epi_plain(Y, D, W(h, p + ".self_attn.out_proj.bias"));
     eo.res = xin; eo.ldres = D;
@@ -670,7 +681,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     HIPCK(hipMemcpyAsync(out->local_output_tap, UNI, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
 
   // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
-  const int NT = (int)L.n_dec_tok;
+  const int NT = (int)L.n_dec_tok, NN = (int)L.n_need;
   float* UDEC = UNI + (size_t)P * D;
   if (NT > 0 && c.dec_layers > 0) {
     {
@@ -679,29 +690,49 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     }
     for (int i = 0; i < c.dec_layers; ++i) {
       const std::string p = "glocal_transformer.global_attention.layers." + std::to_string(i);
-      float* gout = (i == c.dec_layers - 1) ? UDEC : G;
-      EpiLinear eq = epi_plain(QKV, 3 * D, W(h, p + ".multihead2.in_proj_bias"));
-      eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
-      if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, W(h, p + ".multihead2.in_proj_weight"), NT, 3 * D, D, eq))) return rc;
+      const bool last = i == c.dec_layers - 1;
+      // The last layer only has to produce the NN rows the heads read (see build_layout): K and V are
+      // still projected for every token, but Q, the output projection, LayerNorm and the FFN run on
+      // the needed rows alone (gathered A operand, compact [NN, D] outputs).
+      const int MQ = last ? NN : NT;
+      const int* rows = last ? need : nullptr;
+      const float* Win = W(h, p + ".multihead2.in_proj_weight");
+      const float* bin = W(h, p + ".multihead2.in_proj_bias");
+      if (!last) {
+        EpiLinear eq = epi_plain(QKV, 3 * D, bin);
+        eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
+        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win, NT, 3 * D, D, eq))) return rc;
+      } else {
+        EpiLinear ekv = epi_plain(QKV + D, 3 * D, bin + D);                 // k | v columns, all tokens
+        ekv.rowbias = h->dec[i].posbias + D; ekv.rowslot = slot; ekv.rb_cols = D; ekv.rb_ld = 2 * D;
+        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win + (size_t)D * D, NT, 2 * D, D, ekv))) return rc;
+        EpiLinear eq = epi_plain(QKV, 3 * D, bin);                          // q columns, needed rows only
+        eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = D; eq.rb_ld = 2 * D;
+        eq.out_rowidx = need;
+        if ((rc = run_linear(h, s, GemmOperand{G, D, need}, Win, NN, D, D, eq))) return rc;
+      }
       {
-        ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * NT * L.max_dec * D, 4.0 * NT * 4 * D);
-        HIPCK(launch_attention(s, QKV, dec_off, dec_len, L.n_dec_seq, L.max_dec, ATT, D, c.nhead));
+        ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * MQ * L.max_dec * D, 4.0 * (MQ * 2.0 + NT * 2.0) * D);
+        HIPCK(launch_attention(s, QKV, dec_off, dec_len, last ? qbegin : nullptr, L.n_dec_seq, L.max_dec, ATT, D,
+                               c.nhead));
       }
       EpiLinear eo = epi_plain(Y, D, W(h, p + ".multihead2.out_proj.bias"));
-      eo.res = G; eo.ldres = D;
-      if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".multihead2.out_proj.weight"), NT, D, D, eo))) return rc;
+      eo.res = G; eo.ldres = D; eo.res_rowidx = rows;
+      if ((rc = run_linear(h, s, GemmOperand{ATT, D, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
       {
-        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * NT * D);
-        HIPCK(launch_layernorm(s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, NT, D));
+        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D);
+        HIPCK(launch_layernorm(s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, MQ, D));
       }
-      if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), NT, F, D,
+      if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), MQ, F, D,
                            epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
-      EpiLinear e2 = epi_plain(gout, D, W(h, p + ".linear2.bias"));
+      EpiLinear e2 = epi_plain(last ? UDEC : G, D, W(h, p + ".linear2.bias"));
       e2.res = H; e2.ldres = D;
-      if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), NT, D, F, e2))) return rc;
+      if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), MQ, D, F, e2))) return rc;
     }
   } else if (NT > 0) {
-    HIPCK(launch_gather_rows(s, UNI, dec_src, UDEC, NT, D));   // dec_layers == 0: windows pass through
+    // dec_layers == 0: windows pass through -- the needed rows are encoder rows
+    HIPCK(launch_gather_rows(s, UNI, dec_src, G, NT, D));
+    HIPCK(launch_gather_rows(s, G, need, UDEC, NN, D));
   }
   if (out->global_output_tap) HIPCK(launch_gather_rows(s, UNI, out_src, out->global_output_tap, P, D));
 
@@ -781,7 +812,7 @@ int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32
                            int32_t max_len, float* out, int64_t tokens, int32_t dim, int32_t nhead, void* stream) {
   (void)tokens;
   if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
-  return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, num_seq, max_len, out, dim,
+  return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, nullptr, num_seq, max_len, out, dim,
                           nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
