@@ -37,6 +37,9 @@ enum {
 
 enum { STTRAN_MODE_PREDCLS = 0, STTRAN_MODE_SGCLS = 1, STTRAN_MODE_SGDET = 2 };
 enum { STTRAN_DTYPE_F32 = 0, STTRAN_DTYPE_I64 = 1, STTRAN_DTYPE_I32 = 2 };
+/* STTRAN: lib/sttran.py::STTran.  DSG_DETR: lib/dsg_detr.py::STTran (same fusion front-end and heads;
+ * stock encoder layers per frame and per object-class sequence; sgdet mode only). */
+enum { STTRAN_MODEL_STTRAN = 0, STTRAN_MODEL_DSG_DETR = 1 };
 
 /* Constructor arguments of `STTran.__init__` (lib/sttran.py:316-318) that shape the compute. */
 typedef struct SttranConfig {
@@ -53,6 +56,7 @@ typedef struct SttranConfig {
   int32_t embed_dim;           /* 1936 (lib/sttran.py:358) */
   int32_t nhead;               /* 8 */
   int32_t ffn_dim;             /* 2048 */
+  int32_t model;               /* STTRAN_MODEL_* */
 } SttranConfig;
 
 /* The `entry` dict read by STTran.forward.  All tensor pointers are DEVICE

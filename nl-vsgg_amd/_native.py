@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsttran_hip.so")
 STTRAN_OK = 0
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "WEIGHTS", 5: "ORDER", 6: "LIMIT"}
 MODE = {"predcls": 0, "sgcls": 1, "sgdet": 2}
+MODEL_STTRAN, MODEL_DSG_DETR = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_I32 = 0, 1, 2
 PROF_CLASSES = 8
 PROF_NAMES = ["gemm", "union_conv", "mask_conv", "attention", "layernorm", "index", "other", "_"]
@@ -26,7 +27,7 @@ class SttranConfig(C.Structure):
                 ("attention_classes", C.c_int32), ("spatial_classes", C.c_int32),
                 ("contact_classes", C.c_int32), ("num_obj_classes", C.c_int32),
                 ("feat_dim", C.c_int32), ("embed_dim", C.c_int32), ("nhead", C.c_int32),
-                ("ffn_dim", C.c_int32)]
+                ("ffn_dim", C.c_int32), ("model", C.c_int32)]
 
 
 class SttranInputs(C.Structure):

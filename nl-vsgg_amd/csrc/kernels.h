@@ -48,6 +48,9 @@ constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel acc
 hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
                               int dim);
 
+hipError_t launch_gather_add_rows(hipStream_t s, const float* src, const int* idx, const float* table,
+                                  const int* tidx, float* dst, int64_t rows, int dim);
+
 // ---- ObjectClassifier sgdet+wks (lib/sttran.py:173-184) ---------------------------------------
 // z[b] = [features[b] | distribution[b] @ E0 | ReLU(Linear(BN(center_size(box))))]   -> [B, 2376]
 hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,

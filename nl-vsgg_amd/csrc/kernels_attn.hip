@@ -426,4 +426,26 @@ hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, f
   return hipGetLastError();
 }
 
+// dst[r, :] = src[idx[r], :] + table[tidx[r], :]   (DSG-DETR: sequence gather + sinusoidal PE,
+// lib/dsg_detr.py:42-46,556-559)
+__global__ void __launch_bounds__(256)
+gather_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ table,
+                       const int* __restrict__ tidx, float* __restrict__ dst, int64_t rows, int n4) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * n4;
+  const f32x4* t = reinterpret_cast<const f32x4*>(table) + (int64_t)tidx[row] * n4;
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * n4;
+  for (int j = threadIdx.x; j < n4; j += 256) d[j] = s[j] + t[j];
+}
+
+hipError_t launch_gather_add_rows(hipStream_t s, const float* src, const int* idx, const float* table,
+                                  const int* tidx, float* dst, int64_t rows, int dim) {
+  if (rows <= 0) return hipSuccess;
+  if (dim & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_add_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, idx, table, tidx, dst, rows,
+                     dim >> 2);
+  return hipGetLastError();
+}
+
 }  // namespace sttran

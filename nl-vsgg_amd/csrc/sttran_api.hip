@@ -150,7 +150,20 @@ void declare_weights(SttranHandle* h) {
   add_linear(h, "vr_fc", 512, 256 * 49, true);
   add(h, "obj_embed.weight", {NC, 200}, true);
   add(h, "obj_embed2.weight", {NC, 200}, true);
-  for (int i = 0; i < c.enc_layers; ++i) {
+  if (c.model == STTRAN_MODEL_DSG_DETR) {
+    // lib/dsg_detr.py:497-506: sinusoid table + stock encoder layers (1 spatial, 3 temporal)
+    add(h, "positional_encoder.pe", {1, 400, D}, true);
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = i == 0 ? std::string("local_transformer.layers.0")
+                                   : "global_transformer.layers." + std::to_string(i - 1);
+      add_mha(h, p + ".self_attn", D);
+      add_linear(h, p + ".linear1", F, D, true);
+      add_linear(h, p + ".linear2", D, F, true);
+      add(h, p + ".norm1.weight", {D}, true); add(h, p + ".norm1.bias", {D}, true);
+      add(h, p + ".norm2.weight", {D}, true); add(h, p + ".norm2.bias", {D}, true);
+    }
+  }
+  for (int i = 0; i < (c.model == STTRAN_MODEL_DSG_DETR ? 0 : c.enc_layers); ++i) {
     const std::string p = "glocal_transformer.local_attention.layers." + std::to_string(i);
     add_mha(h, p + ".self_attn", D);
     add_linear(h, p + ".linear1", F, D, true);
@@ -158,14 +171,14 @@ void declare_weights(SttranHandle* h) {
     add(h, p + ".norm1.weight", {D}, true); add(h, p + ".norm1.bias", {D}, true);
     add(h, p + ".norm2.weight", {D}, true); add(h, p + ".norm2.bias", {D}, true);
   }
-  for (int i = 0; i < c.dec_layers; ++i) {
+  for (int i = 0; i < (c.model == STTRAN_MODEL_DSG_DETR ? 0 : c.dec_layers); ++i) {
     const std::string p = "glocal_transformer.global_attention.layers." + std::to_string(i);
     add_mha(h, p + ".multihead2", D);
     add_linear(h, p + ".linear1", F, D, true);
     add_linear(h, p + ".linear2", D, F, true);
     add(h, p + ".norm3.weight", {D}, true); add(h, p + ".norm3.bias", {D}, true);
   }
-  add(h, "glocal_transformer.position_embedding.weight", {2, D}, true);
+  if (c.model != STTRAN_MODEL_DSG_DETR) add(h, "glocal_transformer.position_embedding.weight", {2, D}, true);
   add_linear(h, "a_rel_compress", c.attention_classes, D, true);
   add_linear(h, "s_rel_compress", c.spatial_classes, D, true);
   add_linear(h, "c_rel_compress", c.contact_classes, D, true);
@@ -215,6 +228,41 @@ EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu = 0) {
   EpiLinear e{};
   e.C = C; e.ldc = ldc; e.bias = bias; e.relu = relu;
   return e;
+}
+
+// One post-norm encoder layer over ragged sequences (lib/transformer.py:20-30; also the stock
+// nn.TransformerEncoderLayer of lib/dsg_detr.py:502-506 -- same sub-module names):
+//   h = LN1(x + MHA(x,x,x));  out = LN2(h + W2 relu(W1 h + b1) + b2)
+int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, const float* xin, float* xout, int M,
+                      const int* seq_off, const int* seq_len, int nseq, int maxlen) {
+  const SttranConfig& c = h->cfg;
+  const int D = c.embed_dim, F = c.ffn_dim;
+  float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
+  float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>();
+  int rc;
+  if ((rc = run_linear(h, s, GemmOperand{xin, D, nullptr}, W(h, p + ".self_attn.in_proj_weight"), M, 3 * D, D,
+                       epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
+  {
+    ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * M * maxlen * D, 4.0 * M * 4 * D);
+    HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, D, c.nhead));
+  }
+  EpiLinear eo = epi_plain(Y, D, W(h, p + ".self_attn.out_proj.bias"));
+  eo.res = xin; eo.ldres = D;
+  if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".self_attn.out_proj.weight"), M, D, D, eo))) return rc;
+  {
+    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
+    HIPCK(launch_layernorm(s, Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, M, D));
+  }
+  if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
+                       epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
+  EpiLinear e2 = epi_plain(Y, D, W(h, p + ".linear2.bias"));
+  e2.res = H; e2.ldres = D;
+  if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2))) return rc;
+  {
+    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
+    HIPCK(launch_layernorm(s, Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, M, D));
+  }
+  return STTRAN_OK;
 }
 
 int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
@@ -302,6 +350,53 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
   L.total_ints = buf.size();
 }
 
+// DSG-DETR index maps (lib/dsg_detr.py:536-555).  Spatial sequences = frames (as above).  Temporal
+// sequences = one per object class present, its pairs in pair order; the PE row of a token is the
+// dense rank of the pair's subject box (one person box per frame) among the sequence's subjects.
+// Stored in the STTran slots: dec_off/dec_len = class sequences, dec_src = pair of each token,
+// need = PE row of each token, out_src = P + token of each pair.
+void build_layout_dsg(const std::vector<int32_t>& counts, int64_t P, const int64_t* pair_idx, const int64_t* labels,
+                      std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+  const int T = (int)counts.size();
+  std::vector<int32_t> enc_off, enc_len, cls_off, cls_len, tok_pair, tok_pos, out_src(P);
+  L = SttranHandle::Layout();
+  int64_t o = 0;
+  for (int t = 0; t < T; ++t) {
+    if (counts[t] > 0) { enc_off.push_back((int32_t)o); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
+    o += counts[t];
+  }
+  std::map<int64_t, std::vector<int32_t>> by_class;
+  for (int64_t p = 0; p < P; ++p) by_class[labels[pair_idx[2 * p + 1]]].push_back((int32_t)p);
+  for (auto& kv : by_class) {
+    const std::vector<int32_t>& pairs = kv.second;
+    std::vector<int64_t> subj;
+    for (int32_t p : pairs) subj.push_back(pair_idx[2 * (int64_t)p]);
+    std::vector<int64_t> uniq(subj);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    cls_off.push_back((int32_t)tok_pair.size());
+    cls_len.push_back((int32_t)pairs.size());
+    L.max_dec = std::max(L.max_dec, (int)pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+      out_src[pairs[i]] = (int32_t)(P + tok_pair.size());
+      tok_pair.push_back(pairs[i]);
+      tok_pos.push_back((int32_t)(std::lower_bound(uniq.begin(), uniq.end(), subj[i]) - uniq.begin()));
+    }
+  }
+  L.n_enc_seq = (int)enc_off.size();
+  L.n_dec_seq = (int)cls_off.size();
+  L.n_dec_tok = P;
+  L.n_need = P;
+  buf.clear();
+  auto put = [&](const std::vector<int32_t>& v) { size_t off = buf.size(); buf.insert(buf.end(), v.begin(), v.end()); return off; };
+  L.o_enc_off = put(enc_off); L.o_enc_len = put(enc_len);
+  L.o_dec_off = put(cls_off); L.o_dec_len = put(cls_len);
+  L.o_dec_src = put(tok_pair); L.o_out_src = put(out_src);
+  L.o_need = put(tok_pos); L.o_qbegin = buf.size();
+  L.o_slot = buf.size();
+  L.total_ints = buf.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -317,6 +412,10 @@ int sttran_create(const SttranConfig* cfg, SttranHandle** out) {
       cfg->num_obj_classes > 64 || cfg->embed_dim != 1536 + 400 ||
       cfg->attention_classes + cfg->spatial_classes + cfg->contact_classes > 64)
     return STTRAN_ERR_INVALID;
+  if (cfg->model != STTRAN_MODEL_STTRAN && cfg->model != STTRAN_MODEL_DSG_DETR) return STTRAN_ERR_INVALID;
+  // DSG-DETR: only the sgdet branch of the reference runs (lib/dsg_detr.py predcls feeds 2376-d features
+  // into Linear(2048, 512))
+  if (cfg->model == STTRAN_MODEL_DSG_DETR && cfg->mode != STTRAN_MODE_SGDET) return STTRAN_ERR_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
     return STTRAN_ERR_HIP;
@@ -445,7 +544,7 @@ int sttran_finalize_weights(SttranHandle* h) {
   }
   // position embedding folded into a per-slot bias of the q/k projections:
   //   (g + pos) Wqk^T + b = g Wqk^T + (pos Wqk^T) + b      (lib/transformer.py:51, pos is one of 2 rows)
-  for (int i = 0; i < c.dec_layers; ++i) {
+  for (int i = 0; i < (c.model == STTRAN_MODEL_DSG_DETR ? 0 : c.dec_layers); ++i) {
     const std::string pre = "glocal_transformer.global_attention.layers." + std::to_string(i) + ".multihead2";
     GemmOperand A{W(h, "glocal_transformer.position_embedding.weight"), D, nullptr, 0};
     EpiLinear e = epi_plain(h->dec[i].posbias, 2 * D, nullptr);
@@ -555,9 +654,25 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   }
 
   // ---- index maps (cached while the layout repeats) -----------------------------------------
-  if (!(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips)) {
+  const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
+  if (is_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips)) {
     std::vector<int32_t> buf;
-    build_layout(counts, clips, P, buf, h->lay);
+    if (is_dsg) {
+      // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
+      // second model on the shared kernels, not the latency path
+      if (in->num_clips != 1) return fail(h, STTRAN_ERR_INVALID, "forward: DSG-DETR takes one clip per call");
+      std::vector<int64_t> hp((size_t)P * 2), hl((size_t)B);
+      HIPCK(hipMemcpyAsync(hp.data(), in->pair_idx, hp.size() * 8, hipMemcpyDeviceToHost, s));
+      HIPCK(hipMemcpyAsync(hl.data(), in->labels, hl.size() * 8, hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
+      for (int64_t p = 0; p < 2 * P; ++p)
+        if (hp[p] < 0 || hp[p] >= B) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx out of range");
+      build_layout_dsg(counts, P, hp.data(), hl.data(), buf, h->lay);
+      for (size_t i = 0; i < (size_t)P; ++i)
+        if (buf[h->lay.o_need + i] >= 400) return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence");
+    } else {
+      build_layout(counts, clips, P, buf, h->lay);
+    }
     if (h->lay.max_enc > kAttnMaxKeys || h->lay.max_dec > kAttnMaxKeys)
       return fail(h, STTRAN_ERR_LIMIT, "forward: a frame/window exceeds the attention key limit");
     const int k = h->stage_next;
@@ -573,7 +688,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
     HIPCK(hipMemcpyAsync(h->idx.p, h->stage[k], buf.size() * 4, hipMemcpyHostToDevice, s));
     HIPCK(hipEventRecord(h->stage_ev[k], s));
-    h->cached_P = P; h->cached_counts = counts; h->cached_clips = clips;
+    h->cached_P = is_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
   }
   const SttranHandle::Layout& L = h->lay;
   const int32_t* ib = h->idx.as<int32_t>();
@@ -648,41 +763,39 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     HIPCK(hipMemcpyAsync(out->rel_features_tap, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
 
   // ---- spatial encoder, one sequence per non-empty frame (lib/transformer.py:20-30,144) --------
+  const bool dsg = c.model == STTRAN_MODEL_DSG_DETR;
   const float* xin = X0;
-  for (int i = 0; i < c.enc_layers; ++i) {
-    const std::string p = "glocal_transformer.local_attention.layers." + std::to_string(i);
-    float* xout = (i == c.enc_layers - 1) ? UNI : E;
-    if ((rc = run_linear(h, s, GemmOperand{xin, D, nullptr}, W(h, p + ".self_attn.in_proj_weight"), (int)P, 3 * D, D,
-                         epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
-    {
-      ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * P * L.max_enc * D, 4.0 * P * 4 * D);
-      HIPCK(launch_attention(s, QKV, enc_off, enc_len, nullptr, L.n_enc_seq, L.max_enc, ATT, D, c.nhead));
-    }
-    EpiLinear eo = epi_plain(Y, D, W(h, p + ".self_attn.out_proj.bias"));
-    eo.res = xin; eo.ldres = D;
-    if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".self_attn.out_proj.weight"), (int)P, D, D, eo))) return rc;
-    {
-      ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * P * D);
-      HIPCK(launch_layernorm(s, Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, P, D));
-    }
-    if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), (int)P, F, D,
-                         epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
-    EpiLinear e2 = epi_plain(Y, D, W(h, p + ".linear2.bias"));
-    e2.res = H; e2.ldres = D;
-    if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), (int)P, D, F, e2))) return rc;
-    {
-      ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * P * D);
-      HIPCK(launch_layernorm(s, Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, P, D));
-    }
+  const int n_enc_layers = dsg ? 1 : c.enc_layers;
+  for (int i = 0; i < n_enc_layers; ++i) {
+    const std::string p = (dsg ? "local_transformer.layers." : "glocal_transformer.local_attention.layers.") +
+                          std::to_string(i);
+    float* xout = (i == n_enc_layers - 1) ? UNI : E;
+    if ((rc = run_encoder_layer(h, s, p, xin, xout, (int)P, enc_off, enc_len, L.n_enc_seq, L.max_enc))) return rc;
     xin = xout;
   }
-  if (c.enc_layers == 0) HIPCK(hipMemcpyAsync(UNI, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+  if (n_enc_layers == 0) HIPCK(hipMemcpyAsync(UNI, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
   if (out->local_output_tap)
     HIPCK(hipMemcpyAsync(out->local_output_tap, UNI, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
 
-  // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
   const int NT = (int)L.n_dec_tok, NN = (int)L.n_need;
   float* UDEC = UNI + (size_t)P * D;
+  if (dsg) {
+    // ---- DSG-DETR temporal encoder (lib/dsg_detr.py:545-564): one sequence per object class over the
+    //      whole clip, sinusoidal PE by the pair's frame rank inside its sequence, 3 encoder layers.
+    //      dec_src = pair of each sequence token, need = its PE row, dec_off/len = class sequences.
+    {
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 12.0 * P * D);
+      HIPCK(launch_gather_add_rows(s, UNI, dec_src, W(h, "positional_encoder.pe"), need, G, P, D));
+    }
+    const float* gin = G;
+    for (int i = 0; i < 3; ++i) {
+      float* gout = (i == 2) ? UDEC : (i == 0 ? E : G);
+      if ((rc = run_encoder_layer(h, s, "global_transformer.layers." + std::to_string(i), gin, gout, (int)P, dec_off,
+                                  dec_len, L.n_dec_seq, L.max_dec))) return rc;
+      gin = gout;
+    }
+  } else
+  // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
   if (NT > 0 && c.dec_layers > 0) {
     {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D);

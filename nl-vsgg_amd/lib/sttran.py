@@ -38,6 +38,8 @@ def _host_i32(x):
 class STTran:
     """Inference-only STTran (PredCls, and SGDet with `is_wks=True`)."""
 
+    _model = nat.MODEL_STTRAN
+
     def __init__(self, mode="sgdet", attention_class_num=None, spatial_class_num=None, contact_class_num=None,
                  obj_classes=None, enc_layer_num=None, dec_layer_num=None, transformer_mode=None, is_wks=True,
                  feat_dim=2048, motifs_path=None, conf=None):
@@ -115,7 +117,7 @@ class STTran:
             enc_layers=self.enc_layer_num, dec_layers=self.dec_layer_num,
             attention_classes=int(self.attention_class_num), spatial_classes=int(self.spatial_class_num),
             contact_classes=int(self.contact_class_num), num_obj_classes=len(self.obj_classes),
-            feat_dim=self.feat_dim, embed_dim=1936, nhead=8, ffn_dim=2048)
+            feat_dim=self.feat_dim, embed_dim=1936, nhead=8, ffn_dim=2048, model=self._model)
         h = C.c_void_p()
         rc = self._lib.sttran_create(C.byref(cfg), C.byref(h))
         if rc != nat.STTRAN_OK:

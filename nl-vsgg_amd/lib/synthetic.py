@@ -176,6 +176,37 @@ def make_sttran_state_dict(seed: int, enc_layers: int = 1, dec_layers: int = 3,
     return sd
 
 
+def sinusoid_table(max_len: int, d_model: int) -> np.ndarray:
+    """`PositionalEncoding.pe` (lib/dsg_detr.py:27-36): float32 arithmetic as torch does it."""
+    position = np.arange(max_len, dtype=np.float32)[:, None]
+    div = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * np.float32(-np.log(10000.0) / d_model)).astype(np.float32)
+    pe = np.zeros((1, max_len, d_model), dtype=np.float32)
+    pe[0, :, 0::2] = np.sin(position * div)
+    pe[0, :, 1::2] = np.cos(position * div)
+    return pe
+
+
+def _encoder_layer(sd, seed, p, d, ff):
+    _mha(sd, seed, p + ".self_attn", d)
+    _linear(sd, seed, p + ".linear1", ff, d)
+    _linear(sd, seed, p + ".linear2", d, ff)
+    _affine(sd, seed, p + ".norm1", d)
+    _affine(sd, seed, p + ".norm2", d)
+
+
+def make_dsg_detr_state_dict(seed: int) -> dict:
+    """The tensors of `lib/dsg_detr.py::STTran` (:464-511) that its sgdet forward reads.  The d=2376
+    object encoder (`object_classifier.encoder_tran`, 82 M parameters) is never evaluated on that
+    branch (`is_wks` is hard-coded, :89,277-288) and is left out; `strict=False` loading ignores it."""
+    base = make_sttran_state_dict(seed, enc_layers=0, dec_layers=0)
+    sd = {k: v for k, v in base.items() if not k.startswith("glocal_transformer.")}
+    sd["positional_encoder.pe"] = sinusoid_table(400, EMBED_DIM)
+    _encoder_layer(sd, seed, "local_transformer.layers.0", EMBED_DIM, FFN_DIM)
+    for i in range(3):
+        _encoder_layer(sd, seed, f"global_transformer.layers.{i}", EMBED_DIM, FFN_DIM)
+    return sd
+
+
 # --------------------------------------------------------------------------------------
 # entries
 # --------------------------------------------------------------------------------------

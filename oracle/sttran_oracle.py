@@ -248,3 +248,58 @@ def sttran_forward(entry, sd, mode="predcls", enc_layers=1, dec_layers=3, dtype=
     out["spatial_distribution"] = _sigmoid(_lin(g, sd["s_rel_compress.weight"], sd["s_rel_compress.bias"]))
     out["contacting_distribution"] = _sigmoid(_lin(g, sd["c_rel_compress.weight"], sd["c_rel_compress.bias"]))
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# DSG-DETR variant (lib/dsg_detr.py:514-572), sgdet branch (the only one that runs)
+# ---------------------------------------------------------------------------------------
+def torch_encoder_layer(x, sd, p):
+    """stock nn.TransformerEncoderLayer, post-norm, ReLU (lib/dsg_detr.py:21,502-506): the same
+    math as `encoder_layer` above under torch's parameter names."""
+    return encoder_layer(x, sd, p)
+
+
+def dsg_detr_sequences(pair_idx, obj_class):
+    """Temporal sequences of DSG-DETR (lib/dsg_detr.py:545-555): one per object class present, the
+    pairs of that class in pair order; position index = dense rank of the pair's subject box (one
+    person box per frame) inside the sequence."""
+    seqs, poss = [], []
+    for l in np.unique(obj_class):
+        k = np.nonzero(obj_class == l)[0]
+        _, inv = np.unique(pair_idx[k, 0], return_inverse=True)
+        seqs.append(k)
+        poss.append(inv.astype(np.int64))
+    return seqs, poss
+
+
+def dsg_detr_forward(entry, sd, mode="sgdet", dtype=np.float32, stages=None):
+    sd = _cast(sd, np.dtype(dtype))
+    out = object_classifier(entry, sd, mode)                               # :277-288 (== STTran A7)
+    rel = pair_fusion(entry, sd, out["pred_labels"])                       # :517-532
+    if stages is not None:
+        stages["rel_features"] = rel.copy()
+    pi = entry["pair_idx"]
+    frames = entry["boxes"][pi[:, 1], 0].astype(np.int64)                  # :536
+    if np.any(np.diff(frames) < 0):
+        raise ValueError("pairs must be sorted by frame")
+    loc = np.empty_like(rel)
+    for f in np.unique(frames):                                            # :537-543 spatial encoder
+        idx = np.nonzero(frames == f)[0]
+        loc[idx] = torch_encoder_layer(rel[idx], sd, "local_transformer.layers.0")
+    if stages is not None:
+        stages["local_output"] = loc.copy()
+    obj_class = out["pred_labels"][pi[:, 1]]
+    seqs, poss = dsg_detr_sequences(pi, obj_class)                         # :545-555
+    pe = sd["positional_encoder.pe"][0]
+    glob = np.zeros_like(rel)
+    for k, pos in zip(seqs, poss):                                         # :556-564 temporal encoder
+        x = loc[k] + (pe[pos] if mode == "sgdet" else pe[: len(k)])
+        for i in range(3):
+            x = torch_encoder_layer(x, sd, f"global_transformer.layers.{i}")
+        glob[k] = x
+    if stages is not None:
+        stages["global_output"] = glob.copy()
+    out["attention_distribution"] = _lin(glob, sd["a_rel_compress.weight"], sd["a_rel_compress.bias"])
+    out["spatial_distribution"] = _sigmoid(_lin(glob, sd["s_rel_compress.weight"], sd["s_rel_compress.bias"]))
+    out["contacting_distribution"] = _sigmoid(_lin(glob, sd["c_rel_compress.weight"], sd["c_rel_compress.bias"]))
+    return out

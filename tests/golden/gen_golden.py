@@ -169,6 +169,57 @@ def run_case(model, name, seed, counts, mode, dump):
     print(f"{name}: P={len(e_np['im_idx'])} wrote sttran_{name}.npz")
 
 
+DSG_CASES = {
+    "dsgdetr_4x3": (201, [2, 2, 2, 2]),
+    "dsgdetr_ragged": (202, [3, 1, 4, 2, 5]),
+}
+
+
+def build_reference_dsg(sd_np):
+    _stub_modules()
+    tv = types.ModuleType("torchvision"); tv.__path__ = []
+    ops = types.ModuleType("torchvision.ops"); ops.__path__ = []
+    bx = types.ModuleType("torchvision.ops.boxes"); bx.box_area = lambda b: None
+    sys.modules.update({"torchvision": tv, "torchvision.ops": ops, "torchvision.ops.boxes": bx})
+    import lib.word_vectors as wv
+    wv.obj_edge_vectors = lambda names, **k: torch.zeros(len(names), 200)
+    import lib.dsg_detr as rd
+    rd.obj_edge_vectors = wv.obj_edge_vectors
+    torch.Tensor.cuda = lambda self, *a, **k: self          # hard-coded .cuda() calls (lib/dsg_detr.py:542,559)
+    classes = ["__background__"] + [f"c{i}" for i in range(36)]
+    m = rd.STTran(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=classes)
+    m.eval()
+    ref_sd = m.state_dict()
+    for k, v in sd_np.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(np.asarray(v).shape), k
+    unused = [k for k in ref_sd if k not in sd_np and "num_batches_tracked" not in k]
+    assert all(k.startswith("object_classifier.encoder_tran.") or k == "object_classifier.positional_encoder.pe"
+               for k in unused), unused
+    # the reference's own sinusoid table must agree with the portable generator's
+    assert np.abs(ref_sd["positional_encoder.pe"].numpy() - sd_np["positional_encoder.pe"]).max() < 1e-4  # float32 sin(399*x)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=False)
+    return m
+
+
+def run_dsg_case(model, name, seed, counts):
+    e_np = syn.make_entry(seed, counts, mode="sgdet", im_idx_dtype=np.int64)
+    entry = {k: torch.from_numpy(v) for k, v in e_np.items() if isinstance(v, np.ndarray) and k != "frame_counts"}
+    grabbed = {}
+    h = model.local_transformer.register_forward_hook(lambda m, a, o: grabbed.__setitem__("local_padded", o.detach().numpy().copy()))
+    with torch.no_grad():
+        pred = model(entry)
+    h.remove()
+    out = {k: pred[k].numpy() for k in ("attention_distribution", "spatial_distribution", "contacting_distribution",
+                                        "distribution")}
+    cnt = np.asarray(counts)
+    out["local_output"] = np.concatenate([grabbed["local_padded"][t, : cnt[t]] for t in range(len(cnt))], axis=0)
+    out.update(pairs_per_frame=cnt.astype(np.int64), entry_seed=np.int64(seed), weight_seed=np.int64(WEIGHT_SEED))
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+        assert np.isfinite(out[k]).all(), (name, k)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: P={len(e_np['im_idx'])} wrote {name}.npz")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -180,6 +231,13 @@ def main():
         if mode not in models:
             models[mode] = build_reference_model(mode, sd)
         run_case(models[mode], name, seed, counts, mode, dump)
+    dsg = None
+    for name, (seed, counts) in DSG_CASES.items():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
+        if dsg is None:
+            dsg = build_reference_dsg(syn.make_dsg_detr_state_dict(WEIGHT_SEED))
+        run_dsg_case(dsg, name, seed, counts)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ def test_version_and_null_handle(native):
 
 def test_struct_sizes(native):
     # the library rejects any struct whose struct_size differs from its own sizeof
-    assert C.sizeof(native.SttranConfig) == 13 * 4
+    assert C.sizeof(native.SttranConfig) == 14 * 4
     assert C.sizeof(native.SttranInputs) == 8 + 16 + 8 + 16 + 8 * 8
     assert C.sizeof(native.SttranOutputs) == 8 + 7 * 8
     assert C.sizeof(native.SttranProfile) == 8 + 4 * 8 * 8

@@ -206,3 +206,42 @@ def test_recall_identical_to_reference_pipeline(case, predcls, golden_dir):
     for k in (10, 20, 50):
         assert ev.result_dict["predcls_mean_recall"][k] == pytest.approx(
             ref["result_dict"]["predcls_mean_recall"][str(k)], abs=1e-12)
+
+
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged"])
+def test_dsg_detr_golden(name, golden_dir):
+    """Second model on the shared kernels (BASELINE.json configs[4]): lib/dsg_detr.py sgdet branch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    sd = syn.make_dsg_detr_state_dict(int(g["weight_seed"]))
+    m = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    m.eval()
+    rep = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    m.taps = True
+    e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
+    pred = m(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS + ("distribution",):
+        np.testing.assert_allclose(pred[k].cpu().numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
+    np.testing.assert_allclose(pred["_tap_local_output"].cpu().numpy(), g["local_output"], atol=2e-3, rtol=0)
+
+
+def test_dsg_detr_oracle_larger_clip():
+    """16x12-shaped clip through DSG-DETR vs the numpy oracle (class sequences span the clip)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
+    from oracle import sttran_oracle as orc
+    sd = syn.make_dsg_detr_state_dict(7)
+    m = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    e = syn.make_entry(333, [11] * 16, mode="sgdet", im_idx_dtype=np.int64)
+    ref = orc.dsg_detr_forward(e, sd, dtype=np.float64)
+    pred = m(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
+    with pytest.raises(NotImplementedError):
+        DSG(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES)
