@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="16x12", choices=["16x12", "64x36"])
     ap.add_argument("--clips-per-step", type=int, default=0, help="0 = default for the workload")
+    ap.add_argument("--model", default="sttran", choices=["sttran", "dsgdetr"],
+                    help="dsgdetr = BASELINE.json configs[4]: lib/dsg_detr.py (sgdet branch) on the same kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -99,15 +101,32 @@ def main():
 
     T, N = (16, 12) if args.workload == "16x12" else (64, 36)
     cps = args.clips_per_step or (8 if args.workload == "16x12" else 1)
-    sd = syn.make_sttran_state_dict(7)
-    model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
-                   obj_classes=CLASSES, enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True,
-                   feat_dim=2048).to(device)
+    if args.model == "dsgdetr":
+        from nl_vsgg_amd.lib.dsg_detr import STTran as DSGDETR
+        cps = 1                                   # one clip per call (class sequences span the clip)
+        sd = syn.make_dsg_detr_state_dict(7)
+        model = DSGDETR(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
+                        obj_classes=CLASSES).to(device)
+    else:
+        sd = syn.make_sttran_state_dict(7)
+        model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
+                       obj_classes=CLASSES, enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True,
+                       feat_dim=2048).to(device)
     model.eval()
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    batch = pack_clips([device_clip(T, N, gen, device) for _ in range(cps)])
+    clips = [device_clip(T, N, gen, device) for _ in range(cps)]
+    if args.model == "dsgdetr":                   # sgdet entry: detector boxes, class distribution, scores
+        c = clips[0]
+        B = c["features"].shape[0]
+        xy = torch.rand(B, 2, device=device, generator=gen) * 300
+        wh = torch.rand(B, 2, device=device, generator=gen) * 150 + 10
+        c["boxes"] = torch.cat([torch.arange(T, device=device).repeat_interleave(N)[:, None].float(), xy, xy + wh], 1)
+        c["distribution"] = torch.softmax(torch.randn(B, 36, device=device, generator=gen), 1)
+        c["scores"] = c["distribution"].max(1).values
+        c["im_idx"] = c["im_idx"].long()
+    batch = pack_clips(clips) if args.model == "sttran" else clips[0]
     P = int(batch["pair_idx"].shape[0])
     model.reserve(P, int(batch["features"].shape[0]))
     gathered = torch.empty((world * P, 26), device=device) if world > 1 else None
@@ -146,8 +165,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {T} frames x {N} boxes x 2048-d region features, STTran PredCls forward "
-                               f"(enc 1 / dec 3 layers, d=1936), inputs resident in HBM",
+        "config": {"workload": (f"synthetic {T} frames x {N} boxes x 2048-d region features, STTran PredCls forward "
+                                f"(enc 1 / dec 3 layers, d=1936), inputs resident in HBM") if args.model == "sttran" else
+                               (f"synthetic {T} frames x {N} boxes x 2048-d region features, DSG-DETR sgdet forward "
+                                f"(1 spatial + 3 temporal encoder layers, d=1936), inputs resident in HBM"),
                    "clips_per_step": cps, "frames_per_clip": T, "boxes_per_frame": N, "pairs_per_step": P,
                    "sharding": f"whole clips, {world} rank(s), RCCL all-gather of predictions" if world > 1
                                else "single GPU"},
@@ -174,7 +195,7 @@ def main():
             "per_class_tflops": {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in prof.items()
                                  if isinstance(v, dict) and v["ms"] > 0 and v["flops"] > 0},
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "sttran":
         result["cpu_baseline"] = cpu_baseline(T, N, sd)
     if rank == 0:
         print(json.dumps(result))

@@ -142,16 +142,24 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // summed, in fixed workgroup order (deterministic), by gemm_fixup_kernel, which then runs the same
 // epilogue.  No inter-workgroup communication inside a launch.
 struct SkRange {
-  int64_t begin, end;
+  int begin, end;
 };
-__host__ __device__ __forceinline__ SkRange sk_range(int b, int G, int64_t total) {
-  return SkRange{(int64_t)b * total / G, (int64_t)(b + 1) * total / G};
+// range of workgroup b out of G over `total` iterations: the first (total % G) workgroups get one
+// iteration more.  base = total / G and rem = total % G come from the host (no device division).
+__host__ __device__ __forceinline__ SkRange sk_range(int b, int base, int rem) {
+  const int lo = b * base + (b < rem ? b : rem);
+  return SkRange{lo, lo + base + (b < rem ? 1 : 0)};
+}
+// workgroup that owns iteration `it`
+__host__ __device__ __forceinline__ int sk_owner(int it, int base, int rem) {
+  const int big = rem * (base + 1);
+  return it < big ? it / (base + 1) : rem + (it - big) / base;
 }
 
 template <class T, class Epi, int PIPE>
 __global__ void __launch_bounds__(T::NT)
-gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps,
-               float* __restrict__ slab, Epi epi) {
+gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
+               int g_sk, int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
@@ -175,15 +183,27 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     }
   }
 
+  // Hybrid schedule: every workgroup first runs dp_per_wg WHOLE tiles (data-parallel, nothing parked),
+  // then the leftover tiles (fewer than one per workgroup) are stream-K'd over g_sk workgroups.
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);      // neighbouring ranges (shared weight panels) on one XCD
-  const int64_t total = (int64_t)tiles * ksteps;
-  const SkRange rg = sk_range(blk, G, total);
+  const int tiles_dp = dp_per_wg * G;
+  const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
 
-  for (int64_t it = rg.begin; it < rg.end;) {
-    const int tile = (int)(it / ksteps);
-    const int ks0 = (int)(it - (int64_t)tile * ksteps);
-    const int ks1 = (int)min((int64_t)ksteps, ks0 + (rg.end - it));
+  int dp_done = 0;
+  for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
+    int tile, ks0, ks1;
+    const bool dp = dp_done < dp_per_wg;
+    if (dp) {
+      tile = blk * dp_per_wg + dp_done;
+      ks0 = 0; ks1 = ksteps;
+      ++dp_done;
+    } else {
+      const int t = it / ksteps;
+      tile = tiles_dp + t;
+      ks0 = it - t * ksteps;
+      ks1 = min(ksteps, ks0 + (rg.end - it));
+    }
     const int nsteps = ks1 - ks0;
     const int m0 = (tile % tiles_m) * BM;          // consecutive tiles share the B panel
     const int n0 = (tile / tiles_m) * BN;
@@ -391,7 +411,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       }
     } else {
       // ---- partial K range: park the raw accumulators (slot 0 = this workgroup's first tile,
-      //      slot 1 = its last), register-major so that every store is 256 contiguous bytes per wave
+      //      slot 1 = its last; only the stream-K region parks), register-major so that every store is 256 contiguous bytes per wave
       float* sp = slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN) + tid;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -400,7 +420,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
           for (int e = 0; e < 16; ++e) sp[((i * TN + j) * 16 + e) * NT] = acc[i][j][e];
     }
-    it += nsteps;
+    if (!dp) it += nsteps;
   }
 }
 
@@ -410,33 +430,41 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 // Tiles computed whole by one workgroup return at once.
 template <class T, class Epi>
 __global__ void __launch_bounds__(T::NT)
-gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int G, const float* __restrict__ slab, Epi epi) {
+gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
+                  const float* __restrict__ slab, Epi epi) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TN = T::TN;
-  const int tile = blockIdx.x;
-  const int64_t total = (int64_t)gridDim.x * ksteps;
-  const int64_t t0 = (int64_t)tile * ksteps, t1 = t0 + ksteps;
-  int b = (int)(t0 * G / total);
-  while (b > 0 && sk_range(b, G, total).begin > t0) --b;
-  while (sk_range(b, G, total).end <= t0) ++b;
-  {
-    const SkRange r = sk_range(b, G, total);
-    if (r.begin <= t0 && r.end >= t1) return;      // not split
-  }
+  const int tile = blockIdx.x;                   // index inside the stream-K (leftover) region
+  const int t0 = tile * ksteps, t1 = t0 + ksteps;
+  const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t1 - 1, sk_base, sk_rem);
+  if (b_lo == b_hi) return;                      // computed whole by one workgroup: nothing parked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 31, fh = lane >> 5;
   const int ij = blockIdx.y, i = ij / TN, j = ij % TN;
   float acc[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (; b < G; ++b) {
-    const SkRange r = sk_range(b, G, total);
-    if (r.begin >= t1) break;
-    if (r.end <= r.begin) continue;
-    const float* sp = slab + ((int64_t)b * 2 + (r.begin >= t0 ? 0 : 1)) * (BM * BN) + (int64_t)ij * 16 * NT + tid;
+  const float* base = slab + (int64_t)ij * 16 * NT + tid;
+  // workgroup b parked this tile in slot 0 if the tile holds the start of b's range, else slot 1;
+  // only b_lo can start before the tile.  Four contributors' loads are in flight together; the sum
+  // order (ascending b) is fixed, so results are reproducible.
+  for (int b = b_lo; b <= b_hi; b += 4) {
+    float v[4][16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += sp[e * NT];
+    for (int u = 0; u < 4; ++u) {
+      const int bb = b + u;
+      const bool ok = bb <= b_hi;
+      const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
+      const float* sp = base + ((int64_t)(ok ? bb : b_lo) * 2 + slot) * (BM * BN);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[u][e] = ok ? sp[e * NT] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += v[u][e];
   }
-  const int m0 = (tile % tiles_m) * BM, n0 = (tile / tiles_m) * BN;
+  const int gt = tiles_dp + tile;                // global tile index
+  const int m0 = (gt % tiles_m) * BM, n0 = (gt / tiles_m) * BN;
   const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
   const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
 #pragma unroll

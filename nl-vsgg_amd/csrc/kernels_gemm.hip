@@ -32,11 +32,20 @@ static int num_cus() {
   return n;
 }
 
-static int grid_of(int tile, int64_t tiles, int64_t ksteps) {
+// Hybrid data-parallel + stream-K schedule of one GEMM: G persistent workgroups each run dp_per_wg whole
+// tiles; the tiles_sk leftover tiles (< G) are cut into g_sk equal iteration ranges.
+struct SkPlan { int G, dp_per_wg, tiles_sk, g_sk; };
+static SkPlan sk_plan(int tile, int64_t tiles, int64_t ksteps) {
   const int64_t g = (int64_t)num_cus() * kTiles[tile].blocks_per_cu;
+  SkPlan p;
+  p.G = (int)std::min<int64_t>(g, std::max<int64_t>(1, tiles * ksteps / 4));
+  p.dp_per_wg = (int)(tiles / p.G);
+  p.tiles_sk = (int)(tiles - (int64_t)p.dp_per_wg * p.G);
   // never cut finer than 4 K-steps per workgroup: below that the per-segment prologue dominates
-  return (int)std::max<int64_t>(1, std::min<int64_t>(g, tiles * ksteps / 4));
+  p.g_sk = (int)std::max<int64_t>(p.tiles_sk ? 1 : 0, std::min<int64_t>(p.G, (int64_t)p.tiles_sk * ksteps / 4));
+  return p;
 }
+static int grid_of(int tile, int64_t tiles, int64_t ksteps) { return sk_plan(tile, tiles, ksteps).G; }
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split) {
   (void)force_split;   // split-K is subsumed by the stream-K schedule
@@ -53,8 +62,9 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
     const double mfma = (double)tiles * ksteps / cus * ti.bm * ti.bn * kBK * 2.0 / 256.0 / ti.eff;
     // ... plus parking and re-reading the partial tiles (~2 per workgroup) at ~2 KB/cycle chip-wide,
     // the second launch, and the per-launch fixed cost
-    const bool split = (tiles % G) != 0;
-    const double fix = split ? 2.0 * std::min<int64_t>(2 * G, 2 * tiles) * ti.bm * ti.bn * 4.0 / 2000.0 + 5000.0 : 0.0;
+    const SkPlan sp = sk_plan(t, tiles, ksteps);
+    const bool split = sp.tiles_sk != 0;
+    const double fix = split ? 2.0 * (sp.g_sk + sp.tiles_sk) * ti.bm * ti.bn * 4.0 / 2000.0 + 5000.0 : 0.0;
     const double time = mfma + fix + 6000.0;
     if (time < best_t) { best_t = time; best = {t, 1}; }
   }
@@ -90,15 +100,19 @@ static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A
   }
   const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
   const int ksteps = (K + kBK - 1) / kBK;
-  const int G = grid_of(tile_id, tiles, ksteps);
-  const int64_t total = (int64_t)tiles * ksteps;
+  const SkPlan sp = sk_plan(tile_id, tiles, ksteps);
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
   bool split = false;
-  for (int b = 1; b < G && !split; ++b) split = (sk_range(b, G, total).begin % ksteps) != 0;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, slab, epi);
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
+                     sp.g_sk, base, rem, slab, epi);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !split) return e;
-  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(tiles, T::TM * T::TN), dim3(T::NT), 0, s, M, N, tm, ksteps, G, slab, epi);
+  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN), dim3(T::NT), 0, s, M, N, tm, ksteps,
+                     sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
   return hipGetLastError();
 }
 
