@@ -44,7 +44,17 @@ struct GemmOperand {
 // (245 columns, 95.7 % full); per K-step each pair contributes one contiguous [32][49] slab
 // (6 272 bytes), copied flat into LDS; fragments are read with ds_read_b32 (lanes = consecutive
 // hw: conflict-free) using the same k-permutation as the A side.
-enum { B_KMAJOR = 0, B_UNION = 1 };
+// B_CONV1 / B_CONV2: implicit-GEMM convolutions of the mask branch (lib/sttran.py:338,342).  Row n of
+// the B operand is an output position (pair, oy, ox), column k = (ci, ky, kx) in the order of
+// `weight.view(Cout, -1)`; elements are gathered from the NCHW input on the fly (no im2col buffer).
+enum { B_KMAJOR = 0, B_UNION = 1, B_CONV1 = 2, B_CONV2 = 3 };
+template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
+template <> struct ConvGeo<B_CONV1> {   // Conv2d(2, 128, kernel 7, stride 2, padding 3) on 27x27 -> 14x14
+  static constexpr int KH = 7, S = 2, PAD = 3, HI = 27, HO = 14, CIN = 2, KREAL = 98;
+};
+template <> struct ConvGeo<B_CONV2> {   // Conv2d(128, 256, kernel 3, padding 1) on 7x7 -> 7x7
+  static constexpr int KH = 3, S = 1, PAD = 1, HI = 7, HO = 7, CIN = 128, KREAL = 1152;
+};
 constexpr int kUPairs = 5, kUHW = 49, kUSlab = kBK * kUHW;     // 1568 floats per pair per K-step
 constexpr int kUStageB = kUPairs * kUSlab;                     // 7840 floats
 
@@ -163,6 +173,8 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
+  constexpr bool CONV = T::BKIND == B_CONV1 || T::BKIND == B_CONV2;
+  using Geo = ConvGeo<T::BKIND>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -216,6 +228,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     const float* pa[AV]; const float* pb[BV];
     bool va[AV], vb[BV];
     int sb[BV];                                    // LDS float offset of each B piece
+    int cy[BV], cx[BV], cm[BV];                    // B_CONV: input row/col origin of the output position; element mask
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + (tid >> 3) + i * (NT >> 3);
@@ -231,6 +244,17 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         vb[i] = idx < kUStageB / 4 && p < B.aux;
         sb[i] = idx < kUStageB / 4 ? BM * kLdsStride + q * kUSlab + f * 4 : -1;
         pb[i] = B.ptr + (int64_t)(vb[i] ? p : 0) * B.ld + f * 4;
+      } else if constexpr (CONV) {
+        const int g = n0 + (tid >> 3) + i * (NT >> 3);
+        vb[i] = g < N;
+        const int gg = vb[i] ? g : 0;
+        const int pr = gg / (Geo::HO * Geo::HO), pos = gg - pr * (Geo::HO * Geo::HO);
+        const int oy = pos / Geo::HO, ox = pos - oy * Geo::HO;
+        cy[i] = oy * Geo::S - Geo::PAD;
+        cx[i] = ox * Geo::S - Geo::PAD;
+        cm[i] = 0;
+        sb[i] = (BM + (tid >> 3) + i * (NT >> 3)) * kLdsStride + kq4;
+        pb[i] = B.ptr + (int64_t)pr * (Geo::CIN * Geo::HI * Geo::HI);
       } else {
         const int g = n0 + (tid >> 3) + i * (NT >> 3);
         vb[i] = g < N;
@@ -238,6 +262,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         pb[i] = B.ptr + (int64_t)(vb[i] ? (B.rowidx ? B.rowidx[g] : g) : 0) * B.ld + kq4;
       }
     }
+    (void)cy; (void)cx; (void)cm;
     f32x4 ra[AV], rb[BV];
     bool kok_a = true, kok_b = true;               // validity of the K range currently held in ra / rb
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -248,11 +273,30 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       kok_a = (k0 + kq4) < k_end;
       kok_b = UNION ? k0 < k_end : kok_a;
       ka = kok_a ? k0 : 0;
-      kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : ka;
+      kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
     };
     auto load_piece = [&](int n) {
-      if (n < AV) ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
-      else rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);
+      if (n < AV) {
+        ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
+      } else if constexpr (CONV) {
+        // four consecutive k = (ci, ky, kx) of one output position: scalar gathers from the NCHW input,
+        // out-of-image / K-tail elements read a clamped address and are zeroed at the LDS write (cm)
+        const int i = n - AV;
+        int m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = kb_src + e;
+          const int ci = k / (Geo::KH * Geo::KH), r = k - ci * (Geo::KH * Geo::KH);
+          const int ky = r / Geo::KH, kx = r - ky * Geo::KH;
+          const int iy = cy[i] + ky, ix = cx[i] + kx;
+          const bool ok = k < Geo::KREAL && k < k_end && (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
+          m |= ok ? (1 << e) : 0;
+          rb[i][e] = pb[i][ok ? (ci * Geo::HI + iy) * Geo::HI + ix : 0];
+        }
+        cm[i] = m;
+      } else {
+        rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);
+      }
     };
     auto store_piece = [&](int n, float* stage) {
       if (n < AV) {
@@ -260,7 +304,14 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             (va[n] && kok_a) ? ra[n] : zero4;
       } else {
         const int i = n - AV;
-        if (!UNION || sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
+        if constexpr (CONV) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (vb[i] && ((cm[i] >> e) & 1)) ? rb[i][e] : 0.f;
+          *reinterpret_cast<f32x4*>(stage + sb[i]) = v;
+        } else if (!UNION || sb[i] >= 0) {
+          *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
+        }
       }
     };
     // fragment group kb of a stage: k = kb*8 + 4*(lane>>5) + {0..3} for A rows and B alike

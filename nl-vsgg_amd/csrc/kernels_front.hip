@@ -1,5 +1,7 @@
 // kernels_front.hip -- pair-fusion front-end of STTran.forward (lib/sttran.py:381-399) and the
 // sgdet ObjectClassifier input builder (lib/sttran.py:173-176).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace sttran {
@@ -46,116 +48,32 @@ hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_
 }
 
 // ------------------------------------------------------------------------------------------
-// mask_conv1_pool: Conv2d(2,128,k7,s2,p3) -> ReLU -> BatchNorm2d(eval) -> MaxPool2d(k3,s2,p1)
-// (lib/sttran.py:338-341).  One workgroup per pair.  Thread <-> conv output position (14x14):
-// its 2x7x7 receptive field lives in registers, the weights are broadcast from LDS as float4,
-// four channels per step; the 14x14 map of those channels goes through LDS to be pooled 3x3/s2.
+// MaxPool2d(kernel 3, stride 2, padding 1) on 14x14 planes -> 7x7 (lib/sttran.py:341); padding acts as
+// -inf.  One thread per output; a 196-float plane is read through L1/L2 by its 49 threads.
 // ------------------------------------------------------------------------------------------
-constexpr int kC1 = 128, kC1K = 98, kC1KP = 100;   // K padded to 100 (float4 rows)
-
 __global__ void __launch_bounds__(256)
-mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict__ w, const float* __restrict__ bias,
-                       const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
-                       float* __restrict__ c2, int P) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ws = smem;                       // [128][100]
-  float* in = ws + kC1 * kC1KP;           // [2][33][33] zero-padded input
-  float* cbuf = in + 2 * 33 * 33 + 2;     // [2][4][196] double-buffered conv maps (+2: keep 16B align)
-  const int p = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < kC1 * kC1KP; i += 256) {
-    const int c = i / kC1KP, k = i - c * kC1KP;
-    ws[i] = (k < kC1K) ? w[c * kC1K + k] : 0.f;
-  }
-  for (int i = tid; i < 2 * 33 * 33; i += 256) {
-    const int ci = i / 1089, r = i - ci * 1089, y = r / 33 - 3, x = r % 33 - 3;
-    in[i] = (y >= 0 && y < 27 && x >= 0 && x < 27) ? masks[((int64_t)p * 2 + ci) * 729 + y * 27 + x] : 0.f;
-  }
-  __syncthreads();
-  const bool active = tid < 196;
-  const int oy = active ? tid / 14 : 0, ox = active ? tid % 14 : 0;
-  float rf[kC1KP];
+maxpool3s2_kernel(const float* __restrict__ c1, float* __restrict__ c2, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t plane = i / 49;
+    const int pp = (int)(i - plane * 49), py = pp / 7, px = pp - py * 7;
+    const float* src = c1 + plane * 196;
+    float m = -INFINITY;
 #pragma unroll
-  for (int k = 0; k < kC1KP; ++k) {
-    if (k < kC1K) {
-      const int ci = k / 49, ky = (k % 49) / 7, kx = k % 7;
-      rf[k] = in[ci * 1089 + (2 * oy + ky) * 33 + 2 * ox + kx];
-    } else rf[k] = 0.f;
-  }
-  // pooling role of this thread: (channel-in-group, pooled position)
-  const int pc = tid / 49, pp = tid % 49, py = pp / 7, px = pp % 7;
-  for (int c0 = 0; c0 < kC1; c0 += 4) {
-    float* cb = cbuf + ((c0 >> 2) & 1) * 4 * 196;
-    if (active) {
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        const int c = c0 + cc;
-        const f32x4* wr = reinterpret_cast<const f32x4*>(ws + c * kC1KP);
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int q = 0; q < kC1KP / 4; ++q) {
-          const f32x4 wv = wr[q];
-          a0 = fmaf(wv[0], rf[4 * q + 0], a0);
-          a1 = fmaf(wv[1], rf[4 * q + 1], a1);
-          a0 = fmaf(wv[2], rf[4 * q + 2], a0);
-          a1 = fmaf(wv[3], rf[4 * q + 3], a1);
-        }
-        float v = fmaxf(a0 + a1 + bias[c], 0.f);
-        cb[cc * 196 + tid] = v * bn_scale[c] + bn_shift[c];
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y = 2 * py + dy, x = 2 * px + dx;
+        if (y >= 0 && y < 14 && x >= 0 && x < 14) m = fmaxf(m, src[y * 14 + x]);
       }
-    }
-    __syncthreads();
-    if (tid < 196) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int y = 2 * py + dy, x = 2 * px + dx;
-          if (y >= 0 && y < 14 && x >= 0 && x < 14) m = fmaxf(m, cb[pc * 196 + y * 14 + x]);
-        }
-      c2[((int64_t)p * kC1 + c0 + pc) * 49 + pp] = m;
-    }
-    // no second barrier: the next step writes the other half of cbuf; the barrier of that step
-    // orders it against this step's reads before this half is written again.
+    c2[i] = m;
   }
 }
 
-hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w, const float* bias,
-                                  const float* bn_scale, const float* bn_shift, float* c2, int P) {
-  const size_t lds = (size_t)(kC1 * kC1KP + 2 * 33 * 33 + 2 + 2 * 4 * 196) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_conv1_pool_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(P), dim3(256), lds, s, masks, w, bias, bn_scale, bn_shift,
-                     c2, P);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// im2col for Conv2d(128,256,k3,p1) on [P,128,7,7]: row (p,hw), column ci*9 + ky*3 + kx -- the
-// order of conv.4.weight.view(256, 1152) (lib/sttran.py:342).
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-im2col3x3_kernel(const float* __restrict__ c2, float* __restrict__ cols, int P) {
-  __shared__ float t[128 * 49];
-  const int p = blockIdx.x;
-  for (int i = threadIdx.x; i < 128 * 49; i += 256) t[i] = c2[(int64_t)p * 128 * 49 + i];
-  __syncthreads();
-  float* dst = cols + (int64_t)p * 49 * 1152;
-  for (int i = threadIdx.x; i < 49 * 1152; i += 256) {
-    const int hw = i / 1152, k = i - hw * 1152;
-    const int ci = k / 9, kk = k - ci * 9, ky = kk / 3, kx = kk - ky * 3;
-    const int y = hw / 7 + ky - 1, x = hw % 7 + kx - 1;
-    dst[i] = (y >= 0 && y < 7 && x >= 0 && x < 7) ? t[ci * 49 + y * 7 + x] : 0.f;
-  }
-}
-
-hipError_t launch_im2col3x3(hipStream_t s, const float* c2, float* cols, int P) {
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(P), dim3(256), 0, s, c2, cols, P);
+hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t planes) {
+  const int64_t total = planes * 49;
+  if (total <= 0) return hipSuccess;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks), dim3(256), 0, s, c1, c2, total);
   return hipGetLastError();
 }
 

@@ -59,7 +59,7 @@ struct SttranHandle {
   // derived parameters
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
-  float *heads_w = nullptr, *heads_b = nullptr;
+  float *heads_w = nullptr, *heads_b = nullptr, *w0_padded = nullptr;
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
   // workspace
@@ -282,7 +282,7 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   HIPCK(h->uni.ensure((size_t)(cp + tok) * D * 4));
   HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
   HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
-  HIPCK(h->cols.ensure((size_t)cp * 49 * 1152 * 4));
+  HIPCK(h->cols.ensure((size_t)cp * 128 * 196 * 4));   // conv1 output [P,128,14,14]
   HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + (size_t)cp * 2 * 4 + 4096));
   if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
     HIPCK(h->zbuf.ensure((size_t)cb * (h->cfg.feat_dim + 328) * 4));
@@ -493,13 +493,14 @@ int sttran_finalize_weights(SttranHandle* h) {
   const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   // arena layout (floats)
-  size_t total = 2 * 128 + 2 * 256 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  size_t total = 2 * 128 + 2 * 256 + 128 * 128 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
   HIPCK(h->derived.ensure(total * 4));
   float* p = h->derived.as<float>();
   auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
   h->bn1_scale = take(128); h->bn1_shift = take(128);
   h->bn2_scale = take(256); h->bn2_shift = take(256);
   h->heads_w = take((size_t)nh * D); h->heads_b = take(64);
+  h->w0_padded = take(128 * 128);
   h->dec.resize(c.dec_layers);
   for (int i = 0; i < c.dec_layers; ++i) h->dec[i].posbias = take(4 * D);
   h->oc_pos_scale = take(4); h->oc_pos_shift = take(4);
@@ -528,6 +529,9 @@ int sttran_finalize_weights(SttranHandle* h) {
     if ((rc = bn("object_classifier.pos_embed.0", 4, h->oc_pos_scale, h->oc_pos_shift))) return rc;
     if ((rc = bn("object_classifier.decoder_lin.1", 1024, h->oc_bn_scale, h->oc_bn_shift))) return rc;
   }
+  // conv.0.weight.view(128, 98) zero-padded to [128][128]: 16-byte aligned K-major rows for the GEMM A side
+  HIPCK(hipMemset(h->w0_padded, 0, 128 * 128 * 4));
+  HIPCK(hipMemcpy2D(h->w0_padded, 128 * 4, W(h, "conv.0.weight"), 98 * 4, 98 * 4, 128, hipMemcpyDeviceToDevice));
   // packed relation heads [a | s | c] (lib/sttran.py:370-372)
   {
     size_t ro = 0;
@@ -705,7 +709,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
   float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>(); float* G = h->gbuf.as<float>();
   float* UNI = h->uni.as<float>(); float* V = h->vbuf.as<float>(); float* C2 = h->c2.as<float>();
-  float* COLS = h->cols.as<float>(); float* E = h->ebuf.as<float>();
+  float* E = h->ebuf.as<float>();
 
   // ---- ObjectClassifier, sgdet + is_wks (lib/sttran.py:173-184) ------------------------------
   if (oc) {
@@ -735,22 +739,20 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   if ((rc = run_linear(h, s, GemmOperand{in->features, FD, obj_idx}, W(h, "obj_fc.weight"), (int)P, 512, FD,
                        epi_plain(X0 + 512, D, W(h, "obj_fc.bias"))))) return rc;
   {
-    ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 6272));
-    HIPCK(launch_mask_conv1_pool(s, in->spatial_masks, W(h, "conv.0.weight"), W(h, "conv.0.bias"), h->bn1_scale,
-                                 h->bn1_shift, C2, (int)P));
-  }
-  {
-    ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 0, 4.0 * P * (6272 + 49.0 * 1152));
-    HIPCK(launch_im2col3x3(s, C2, COLS, (int)P));
-  }
-  {
-    // conv3x3 as GEMM: M = 256 out channels, N = P*49 positions, K = 1152
-    const int M = 256, N = (int)(P * 49), K = 1152;
-    GemmPlan plan = plan_gemm(M, N, K, 0, 1);
-    EpiConvRelBn e{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
-    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
-    HIPCK(gemm_conv(s, GemmOperand{W(h, "conv.4.weight"), K, nullptr}, GemmOperand{COLS, K, nullptr}, M, N, K, e,
-                    plan, h->slab.as<float>()));
+    // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
+    float* C1 = h->cols.as<float>();                    // [P, 128, 14, 14]
+    EpiConvRelBn e1{C1, W(h, "conv.0.bias"), h->bn1_scale, h->bn1_shift, 128, 196};
+    {
+      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 196));
+      HIPCK(launch_mask_conv1(s, h->w0_padded, in->spatial_masks, e1, (int)P, h->slab.as<float>()));
+    }
+    {
+      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 0, 4.0 * P * 128 * (196 + 49));
+      HIPCK(launch_maxpool3s2(s, C1, C2, P * 128));
+    }
+    EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152));
+    HIPCK(launch_mask_conv2(s, W(h, "conv.4.weight"), C2, e2, (int)P, h->slab.as<float>()));
   }
   {
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
