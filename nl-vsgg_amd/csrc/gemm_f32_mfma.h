@@ -46,7 +46,8 @@ struct GemmOperand {
 // hw: conflict-free) using the same k-permutation as the A side.
 // B_CONV1 / B_CONV2: implicit-GEMM convolutions of the mask branch (lib/sttran.py:338,342).  Row n of
 // the B operand is an output position (pair, oy, ox), column k = (ci, ky, kx) in the order of
-// `weight.view(Cout, -1)`; elements are gathered from the NCHW input on the fly (no im2col buffer).
+// `weight.view(Cout, -1)` for B_CONV1 and (ky, kx, ci) for B_CONV2 (its weights are permuted to match
+// when they are loaded); elements are gathered from the NCHW input on the fly (no im2col buffer).
 enum { B_KMAJOR = 0, B_UNION = 1, B_CONV1 = 2, B_CONV2 = 3 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
 template <> struct ConvGeo<B_CONV1> {   // Conv2d(2, 128, kernel 7, stride 2, padding 3) on 27x27 -> 14x14
@@ -278,6 +279,20 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     auto load_piece = [&](int n) {
       if (n < AV) {
         ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
+      } else if constexpr (T::BKIND == B_CONV2) {
+        // K is ordered (ky, kx, ci) for this conv (weights permuted to match at load time), so the four
+        // k of a piece are four consecutive input channels at ONE tap: the tap and its bounds test are
+        // wave-uniform per K-step (128 channels = 4 K-steps per tap), the loads are 49 floats apart
+        const int i = n - AV;
+        const int k0 = kb_src - kq4;                       // uniform
+        const int tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH;
+        const int ci = k0 - tap * Geo::CIN + kq4;
+        const int iy = cy[i] + ky, ix = cx[i] + kx;
+        const bool ok = k0 < k_end && (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
+        const float* src = pb[i] + (ok ? (ci * Geo::HI + iy) * Geo::HI + ix : 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[i][e] = src[ok ? e * Geo::HI * Geo::HI : 0];
+        cm[i] = ok ? 0xF : 0;
       } else if constexpr (CONV) {
         // four consecutive k = (ci, ky, kx) of one output position: scalar gathers from the NCHW input,
         // out-of-image / K-tail elements read a clamped address and are zeroed at the LDS write (cm)

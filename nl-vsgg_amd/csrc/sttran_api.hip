@@ -59,7 +59,7 @@ struct SttranHandle {
   // derived parameters
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
-  float *heads_w = nullptr, *heads_b = nullptr, *w0_padded = nullptr;
+  float *heads_w = nullptr, *heads_b = nullptr, *w0_padded = nullptr, *w4_perm = nullptr;
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
   // workspace
@@ -493,7 +493,7 @@ int sttran_finalize_weights(SttranHandle* h) {
   const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   // arena layout (floats)
-  size_t total = 2 * 128 + 2 * 256 + 128 * 128 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  size_t total = 2 * 128 + 2 * 256 + 128 * 128 + 256 * 1152 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
   HIPCK(h->derived.ensure(total * 4));
   float* p = h->derived.as<float>();
   auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
@@ -501,6 +501,7 @@ int sttran_finalize_weights(SttranHandle* h) {
   h->bn2_scale = take(256); h->bn2_shift = take(256);
   h->heads_w = take((size_t)nh * D); h->heads_b = take(64);
   h->w0_padded = take(128 * 128);
+  h->w4_perm = take(256 * 1152);
   h->dec.resize(c.dec_layers);
   for (int i = 0; i < c.dec_layers; ++i) h->dec[i].posbias = take(4 * D);
   h->oc_pos_scale = take(4); h->oc_pos_shift = take(4);
@@ -532,6 +533,15 @@ int sttran_finalize_weights(SttranHandle* h) {
   // conv.0.weight.view(128, 98) zero-padded to [128][128]: 16-byte aligned K-major rows for the GEMM A side
   HIPCK(hipMemset(h->w0_padded, 0, 128 * 128 * 4));
   HIPCK(hipMemcpy2D(h->w0_padded, 128 * 4, W(h, "conv.0.weight"), 98 * 4, 98 * 4, 128, hipMemcpyDeviceToDevice));
+  // conv.4.weight [256][ci 128][ky 3][kx 3] -> [256][(ky, kx)][ci]: the K order of the B_CONV2 loader
+  {
+    std::vector<float> w(256 * 1152), wp(256 * 1152);
+    HIPCK(hipMemcpy(w.data(), W(h, "conv.4.weight"), w.size() * 4, hipMemcpyDeviceToHost));
+    for (int co = 0; co < 256; ++co)
+      for (int ci = 0; ci < 128; ++ci)
+        for (int t = 0; t < 9; ++t) wp[(size_t)co * 1152 + t * 128 + ci] = w[(size_t)co * 1152 + ci * 9 + t];
+    HIPCK(hipMemcpy(h->w4_perm, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+  }
   // packed relation heads [a | s | c] (lib/sttran.py:370-372)
   {
     size_t ro = 0;
@@ -752,7 +762,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152));
-    HIPCK(launch_mask_conv2(s, W(h, "conv.4.weight"), C2, e2, (int)P, h->slab.as<float>()));
+    HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
   }
   {
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
