@@ -158,7 +158,7 @@ def main():
 
     frames_per_step = world * cps * T
     result = {
-        "metric": "frames/sec (PredCls inference)",
+        "metric": "frames/sec (PredCls inference)" if args.model == "sttran" else "frames/sec (SGDet inference, DSG-DETR)",
         "value": frames_per_step * args.steps / elapsed,
         "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,9 +184,24 @@ def main():
         g = prof["gemm"]
         tot_ms = sum(v["ms"] for k, v in prof.items() if isinstance(v, dict))
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # HBM-side traffic of the same kernel class: PMC counters cannot be read from inside this process;
+        # tools/pmc_traffic.py turns the two rocprofv3 --pmc passes of THIS command (FETCH_SIZE x2 per the
+        # gfx950 correction, WRITE_SIZE) into profiles/*_pmc_traffic_<workload>.json, picked up here.
+        traffic, traffic_src = None, None
+        pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
+                     if p.endswith(f"pmc_traffic_{args.workload}.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if pmc and args.model == "sttran":
+            with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
+                cls = json.load(f)["classes"].get("gemm")
+            if cls:
+                traffic, traffic_src = cls["hbm_bytes_per_launch"], f"profiles/{pmc[-1]}"
         result["roofline"] = {
-            "kernel": "gemm_nt_kernel (fp32 MFMA 32x32x2)", "bound": "mfma", "achieved": ach,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "gemm_sk_kernel + gemm_fixup_kernel (fp32 MFMA 32x32x2, all nn.Linear / conv3x3 launches)",
+            "bound": "mfma", "achieved": ach,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric reads x2 + writes)",
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
             "launches_per_step": g["launches"] / max(prof["forwards"], 1),
             "avg_launch_us": 1e3 * g["ms"] / max(g["launches"], 1),
             "share_of_device_time": g["ms"] / tot_ms if tot_ms else None,

@@ -145,6 +145,14 @@ void sttran_destroy(SttranHandle* h);
 const char* sttran_last_error(SttranHandle* h);
 const char* sttran_version(void);
 
+/* The step immediately before the path: union box and the two soft box masks of every
+ * (subject, object) pair -- `union_boxes` and `draw_union_boxes(pair_rois, 27) - 0.5` of
+ * lib/object_detector.py:110-124 / lib/draw_rectangles/draw_rectangles.pyx:27-67, on the device
+ * instead of a D2H copy + Cython loop + H2D copy.  boxes [B,5] (col 0 = frame id), pair_idx [P,2],
+ * im_idx [P] float (may be NULL), union_boxes [P,5] (may be NULL), spatial_masks [P,2,pool,pool]. */
+int sttran_union_boxes_masks(const float* boxes, const int64_t* pair_idx, const float* im_idx, int64_t num_pairs,
+                             int32_t pool, float* union_boxes, float* spatial_masks, void* stream);
+
 /* profiling (no reference counterpart; SURVEY 5 "Tracing / profiling: none") */
 int sttran_profile_enable(SttranHandle* h, int32_t enable);
 int sttran_profile_reset(SttranHandle* h);

@@ -70,6 +70,8 @@ SYMBOLS = [
     ("sttran_profile_enable", C.c_int, [C.c_void_p, C.c_int32]),
     ("sttran_profile_reset", C.c_int, [C.c_void_p]),
     ("sttran_profile_read", C.c_int, [C.c_void_p, C.POINTER(SttranProfile)]),
+    ("sttran_union_boxes_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     ("sttran_debug_gemm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("sttran_debug_mfma_peak", C.c_int, [C.c_int32, C.POINTER(C.c_double)]),

@@ -37,6 +37,10 @@ hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t 
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
                              int P, int K, float* slab);
 
+// union boxes + soft box masks of each pair (lib/object_detector.py:110-124)
+hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int64_t* pair_idx, const float* im_idx,
+                                    int P, int pool, float* union_boxes, float* masks);
+
 // ---- transformer pieces ----------------------------------------------------------------------
 hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
                             int64_t rows, int dim);

@@ -84,6 +84,58 @@ hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// union_boxes_masks: the step right before the hot path (lib/object_detector.py:110-124), which the
+// reference does with a device->host copy, a Cython loop (lib/draw_rectangles/draw_rectangles.pyx:27-67)
+// and a host->device copy.  Per pair: the union box of subject and object, and the two soft box masks
+//   mask[i][y][x] = clamp01(x+1-x1) * clamp01(x2-x) * clamp01(y+1-y1) * clamp01(y2-y)  - 0.5
+// with the box rescaled into the union box on a pool x pool grid (float32, same operation order).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+union_boxes_masks_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ pair_idx,
+                         const float* __restrict__ im_idx, int P, int pool, float* __restrict__ union_boxes,
+                         float* __restrict__ masks) {
+  const int p = blockIdx.x;
+  if (p >= P) return;
+  __shared__ float bx[8];
+  __shared__ float sc[2][4];      // per box: x1, y1, x2, y2 in pooled coordinates
+  if (threadIdx.x < 8) {
+    const int64_t b = pair_idx[2 * (int64_t)p + (threadIdx.x >> 2)];
+    bx[threadIdx.x] = boxes[b * 5 + 1 + (threadIdx.x & 3)];
+  }
+  __syncthreads();
+  const float x1u = fminf(bx[0], bx[4]), y1u = fminf(bx[1], bx[5]);
+  const float x2u = fmaxf(bx[2], bx[6]), y2u = fmaxf(bx[3], bx[7]);
+  if (threadIdx.x < 2) {
+    const int i = threadIdx.x;
+    const float w = x2u - x1u, h = y2u - y1u, ps = (float)pool;
+    sc[i][0] = (bx[0 + 4 * i] - x1u) * ps / w;
+    sc[i][1] = (bx[1 + 4 * i] - y1u) * ps / h;
+    sc[i][2] = (bx[2 + 4 * i] - x1u) * ps / w;
+    sc[i][3] = (bx[3 + 4 * i] - y1u) * ps / h;
+  }
+  if (union_boxes && threadIdx.x == 0) {
+    float* u = union_boxes + (int64_t)p * 5;
+    u[0] = im_idx ? im_idx[p] : 0.f; u[1] = x1u; u[2] = y1u; u[3] = x2u; u[4] = y2u;
+  }
+  __syncthreads();
+  const int n = pool * pool;
+  for (int t = threadIdx.x; t < 2 * n; t += 256) {
+    const int i = t / n, r = t - i * n, y = r / pool, x = r - y * pool;
+    const float yc = fminf(fmaxf((float)(y + 1) - sc[i][1], 0.f), 1.f) * fminf(fmaxf(sc[i][3] - (float)y, 0.f), 1.f);
+    const float xc = fminf(fmaxf((float)(x + 1) - sc[i][0], 0.f), 1.f) * fminf(fmaxf(sc[i][2] - (float)x, 0.f), 1.f);
+    masks[(int64_t)p * 2 * n + t] = xc * yc - 0.5f;
+  }
+}
+
+hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int64_t* pair_idx, const float* im_idx,
+                                    int P, int pool, float* union_boxes, float* masks) {
+  if (P <= 0) return hipSuccess;
+  hipLaunchKernelGGL(union_boxes_masks_kernel, dim3(P), dim3(256), 0, s, boxes, pair_idx, im_idx, P, pool,
+                     union_boxes, masks);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // objcls_prep: ObjectClassifier input of the sgdet+wks branch (lib/sttran.py:174-176):
 //   z[b] = [ features[b] | distribution[b] @ obj_embed.weight | ReLU(Linear(BN1d(center_size(box)))) ]
 // center_size (lib/fpn/box_utils.py:51-63): wh = xy2 - xy1 + 1, c = xy1 + 0.5 wh.

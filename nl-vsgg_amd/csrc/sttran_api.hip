@@ -888,6 +888,13 @@ int sttran_sync_check(SttranHandle* h, void* stream) {
   return STTRAN_OK;
 }
 
+int sttran_union_boxes_masks(const float* boxes, const int64_t* pair_idx, const float* im_idx, int64_t num_pairs,
+                             int32_t pool, float* union_boxes, float* spatial_masks, void* stream) {
+  if (!boxes || !pair_idx || !spatial_masks || num_pairs < 0 || pool <= 0 || pool > 64) return STTRAN_ERR_INVALID;
+  return launch_union_boxes_masks(reinterpret_cast<hipStream_t>(stream), boxes, pair_idx, im_idx, (int)num_pairs, pool,
+                                  union_boxes, spatial_masks) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
 // ---- kernel-level test hooks -------------------------------------------------------------------
 int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, const float* bias,
                       const float* residual, float* C, int64_t M, int64_t N, int64_t K, int32_t relu,

@@ -50,7 +50,37 @@ def build_bbox():
     sys.modules["h5py"] = types.ModuleType("h5py")
 
 
+def build_draw():
+    """compile the reference's draw_rectangles.pyx out-of-tree and return draw_union_boxes"""
+    tmp = tempfile.mkdtemp(prefix="refdraw_")
+    src = os.path.join(REF, "lib/draw_rectangles/draw_rectangles.pyx")
+    setup = os.path.join(tmp, "setup.py")
+    with open(setup, "w") as f:
+        f.write("from setuptools import setup, Extension\nfrom Cython.Build import cythonize\nimport numpy\n"
+                f"setup(ext_modules=cythonize(Extension('draw_rectangles', [r'{src}'], include_dirs=[numpy.get_include()]),"
+                f" language_level=2, build_dir=r'{tmp}/b'))\n")
+    subprocess.run([sys.executable, setup, "build_ext", "--build-lib", tmp, "--build-temp", tmp + "/t"],
+                   check=True, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, tmp)
+    return importlib.import_module("draw_rectangles").draw_union_boxes
+
+
+def golden_draw():
+    draw = build_draw()
+    e = syn.make_entry(301, [3, 2, 4])
+    pi = e["pair_idx"]
+    rois = np.concatenate([e["boxes"][pi[:, 0], 1:], e["boxes"][pi[:, 1], 1:]], axis=1).astype(np.float32)
+    # a few hand-made edge cases: identical boxes, nested box, touching boxes
+    extra = np.array([[10, 10, 50, 60, 10, 10, 50, 60], [0, 0, 100, 100, 25, 30, 40, 45],
+                      [0, 0, 10, 10, 10, 0, 20, 10]], dtype=np.float32)
+    rois = np.concatenate([rois, extra], axis=0)
+    out = draw(rois, 27)
+    np.savez_compressed(os.path.join(HERE, "draw_union_boxes.npz"), pair_rois=rois, masks=out.astype(np.float32))
+    print("draw_union_boxes", out.shape, float(out.min()), float(out.max()))
+
+
 def main():
+    golden_draw()
     build_bbox()
     from lib.evaluation_recall import SceneGraphEvaluator as RefEval
     for case, mode in CASES.items():
