@@ -505,38 +505,38 @@ gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int g_sk, int sk_base, 
   if (b_lo == b_hi) return;                      // computed whole by one workgroup: nothing parked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 31, fh = lane >> 5;
-  const int ij = blockIdx.y, i = ij / TN, j = ij % TN;
-  float acc[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const float* base = slab + (int64_t)ij * 16 * NT + tid;
+  // blockIdx.y = (register group ij, quarter eq): each thread sums 4 of the 16 accumulator registers of
+  // its lane, so the loads of up to eight contributors (32 per thread) are in flight together and the
+  // grid is four times wider -- the kernel is a latency chain, not a bandwidth problem
+  const int ij = blockIdx.y >> 2, eq = blockIdx.y & 3, i = ij / TN, j = ij % TN;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* base = slab + ((int64_t)ij * 16 + eq * 4) * NT + tid;
   // workgroup b parked this tile in slot 0 if the tile holds the start of b's range, else slot 1;
-  // only b_lo can start before the tile.  Four contributors' loads are in flight together; the sum
-  // order (ascending b) is fixed, so results are reproducible.
-  for (int b = b_lo; b <= b_hi; b += 4) {
-    float v[4][16];
+  // only b_lo can start before the tile.  The sum order (ascending b) is fixed: reproducible.
+  for (int b = b_lo; b <= b_hi; b += 8) {
+    float v[8][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int bb = b + u;
       const bool ok = bb <= b_hi;
       const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
       const float* sp = base + ((int64_t)(ok ? bb : b_lo) * 2 + slot) * (BM * BN);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[u][e] = ok ? sp[e * NT] : 0.f;
+      for (int e = 0; e < 4; ++e) v[u][e] = ok ? sp[e * NT] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] += v[u][e];
+      for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
   }
   const int gt = tiles_dp + tile;                // global tile index
   const int m0 = (gt % tiles_m) * BM, n0 = (gt / tiles_m) * BN;
   const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
-  const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh;
+  const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh + 8 * eq;   // e = 4*eq + r: row = r + 8*eq
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int row = rbase + (e & 3) + 8 * (e >> 2);
-    if (row < M && col < N) epi(row, col, acc[e]);
+  for (int r = 0; r < 4; ++r) {
+    const int row = rbase + r;
+    if (row < M && col < N) epi(row, col, acc[r]);
   }
 }
 
