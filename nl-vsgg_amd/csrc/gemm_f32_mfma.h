@@ -70,15 +70,24 @@ struct EpiLinear {
   const float* shift;
   const float* res; int64_t ldres; const int* res_rowidx;   // residual add, optional gather
   int relu;
-  const int* out_rowidx;    // optional scatter: GEMM row r is written to C row out_rowidx[r]
-  __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    const int orow = out_rowidx ? out_rowidx[row] : row;
-    if (bias) v += bias[col];
+  const int* out_rowidx;    // optional scatter: GEMM row r is written to C row out_rowidx[r] (skipped if < 0)
+  const int* out_rowidx2;   // optional second copy of the same row (skipped if < 0)
+  __device__ __forceinline__ void put(int orow, int row, int col, float v) const {
     if (rowbias && col < rb_cols) v += rowbias[(int)rowslot[orow] * rb_ld + col];
     if (scale) v = v * scale[col] + shift[col];
     if (relu) v = fmaxf(v, 0.f);
     if (res) v += res[(int64_t)(res_rowidx ? res_rowidx[row] : row) * ldres + col];
     C[(int64_t)orow * ldc + col] = v;
+  }
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    if (bias) v += bias[col];
+    if (!out_rowidx) { put(row, row, col, v); return; }
+    const int o1 = out_rowidx[row];
+    if (o1 >= 0) put(o1, row, col, v);
+    if (out_rowidx2) {
+      const int o2 = out_rowidx2[row];
+      if (o2 >= 0) put(o2, row, col, v);
+    }
   }
 };
 

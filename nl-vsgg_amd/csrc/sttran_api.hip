@@ -44,8 +44,8 @@ struct DevBuf {
 struct ProfEvent { hipEvent_t a, b; int cls; };
 
 // worst case of build_layout(): 2P (encoder off/len) + 6P (window off/len/q_begin) + 2P (dec_src) +
-// P (out_src) + P (need_idx) + P/2 (slots) int32 words
-constexpr int64_t kIdxIntsPerPair = 16;
+// P (out_src) + P (need_idx) + 2P (tok0/tok1) + P/2 (slots) int32 words
+constexpr int64_t kIdxIntsPerPair = 18;
 
 struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
 
@@ -79,7 +79,7 @@ struct SttranHandle {
     int n_enc_seq = 0, max_enc = 0, n_dec_seq = 0, max_dec = 0;
     int64_t n_dec_tok = 0, n_need = 0;
     size_t o_enc_off = 0, o_enc_len = 0, o_dec_off = 0, o_dec_len = 0, o_dec_src = 0, o_out_src = 0, o_slot = 0;
-    size_t o_need = 0, o_qbegin = 0;
+    size_t o_need = 0, o_qbegin = 0, o_tok0 = 0, o_tok1 = 0;
     size_t total_ints = 0;
   } lay;
   // profiling
@@ -305,7 +305,7 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
   const int T = (int)counts.size();
   std::vector<int64_t> off(T + 1, 0);
   for (int t = 0; t < T; ++t) off[t + 1] = off[t] + counts[t];
-  std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P), need, qbegin;
+  std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P), need, qbegin, tok0(P, -1), tok1(P, -1);
   std::vector<uint8_t> slot;
   L = SttranHandle::Layout();
   for (int t = 0; t < T; ++t)
@@ -321,7 +321,13 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
       dec_off.push_back(doff);
       dec_len.push_back(n0 + n1);
       L.max_dec = std::max(L.max_dec, n0 + n1);
-      for (int i = 0; i < n0 + n1; ++i) { dec_src.push_back((int32_t)(off[j] + i)); slot.push_back(i < n0 ? 0 : 1); }
+      for (int i = 0; i < n0 + n1; ++i) {
+        // a pair appears as a slot-0 token in the window that starts at its frame and as a slot-1 token in
+        // the window that ends at it: tok0 / tok1 let the first decoder layer project each pair ONCE
+        (i < n0 ? tok0 : tok1)[off[j] + i] = (int32_t)dec_src.size();
+        dec_src.push_back((int32_t)(off[j] + i));
+        slot.push_back(i < n0 ? 0 : 1);
+      }
       // rows of this window the 'latter' scatter reads (lib/transformer.py:179-185): the first window
       // of a clip gives both frames, every other window only its second frame.  Only those rows of the
       // LAST decoder layer are ever consumed, so that layer computes just them (need / q_begin).
@@ -344,6 +350,7 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
   L.o_dec_off = put(dec_off); L.o_dec_len = put(dec_len);
   L.o_dec_src = put(dec_src); L.o_out_src = put(out_src);
   L.o_need = put(need); L.o_qbegin = put(qbegin);
+  L.o_tok0 = put(tok0); L.o_tok1 = put(tok1);
   L.o_slot = buf.size();
   buf.resize(buf.size() + (slot.size() + 3) / 4, 0);
   if (!slot.empty()) memcpy(buf.data() + L.o_slot, slot.data(), slot.size());
@@ -711,6 +718,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   const int* dec_src = ib + L.o_dec_src; const int* out_src = ib + L.o_out_src;
   const uint8_t* slot = reinterpret_cast<const uint8_t*>(ib + L.o_slot);
   const int* need = ib + L.o_need; const int* qbegin = ib + L.o_qbegin;
+  const int* tok0 = ib + L.o_tok0; const int* tok1 = ib + L.o_tok1;
   int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
   int* obj_idx = subj_idx + h->capP;
 
@@ -823,7 +831,15 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       const int* rows = last ? need : nullptr;
       const float* Win = W(h, p + ".multihead2.in_proj_weight");
       const float* bin = W(h, p + ".multihead2.in_proj_bias");
-      if (!last) {
+      if (!last && i == 0) {
+        // first layer: the input rows of a pair's two tokens are the same encoder row, and the position
+        // embedding only enters as a bias, so q|k|v are projected once per PAIR (P rows instead of NT)
+        // and written to both token rows, each with the bias of its own slot
+        EpiLinear eq = epi_plain(QKV, 3 * D, bin);
+        eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
+        eq.out_rowidx = tok0; eq.out_rowidx2 = tok1;
+        if ((rc = run_linear(h, s, GemmOperand{UNI, D, nullptr}, Win, (int)P, 3 * D, D, eq))) return rc;
+      } else if (!last) {
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
         if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win, NT, 3 * D, D, eq))) return rc;
