@@ -28,6 +28,7 @@ SHAPES = {
     "path64": path_shapes(2240, 4410),
     "path16": path_shapes(176, 330),
     "path16x8": path_shapes(1408, 2640),
+    "path16x16": path_shapes(2816, 5280),
 }
 
 
