@@ -91,13 +91,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # one process per GPU; BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only so the N>1 code path can be
+    # smoke-tested on a single-GPU box (all ranks on device 0, gloo instead of RCCL)
+    local = int(os.environ.get("BENCH_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        dist.init_process_group(backend)
 
     T, N = (16, 12) if args.workload == "16x12" else (64, 36)
     cps = args.clips_per_step or (16 if args.workload == "16x12" else 1)
@@ -139,7 +143,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -215,7 +219,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
