@@ -54,23 +54,39 @@ def device_clip(T, N, gen, device):
     }
 
 
-def cpu_baseline(T, N, sd, budget_s=20.0):
+def cpu_baseline(T, N, sd, budget_s=24.0):
     """The numpy oracle (a port of the reference's CPU path, validated against it by the golden
-    tests) timed on this host: one clip per run, as many runs as fit the budget."""
+    tests) timed on this host: one clip per run.  BLAS thread counts 8 / 32 / all cores are tried
+    (small GEMMs oversubscribe a 256-core host) and the fastest setting is reported with its count."""
     from oracle import sttran_oracle as orc
     entry = syn.uniform_clip(11, T, N)
-    t0 = time.perf_counter()
-    orc.sttran_forward(entry, sd)                      # warm-up (BLAS threads, page faults)
-    first = time.perf_counter() - t0
-    runs = []
-    while sum(runs) + first < budget_s and len(runs) < 5:
-        t0 = time.perf_counter()
-        orc.sttran_forward(entry, sd)
-        runs.append(time.perf_counter() - t0)
-    med = float(np.median(runs)) if runs else first
-    return {"value": T / med, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{max(len(runs), 1)} forward(s) of one {T}x{N} clip, numpy/BLAS fp32 oracle, "
-                      f"median {med:.3f} s/clip"}
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                   # threadpoolctl absent: whatever BLAS defaults to
+        threadpool_limits = None
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nthr in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        ctx = threadpool_limits(limits=nthr) if threadpool_limits else None
+        try:
+            t0 = time.perf_counter()
+            orc.sttran_forward(entry, sd)              # warm-up (BLAS threads, page faults)
+            first = time.perf_counter() - t0
+            runs = []
+            while sum(runs) + first < budget_s / 3 and len(runs) < 3:
+                t0 = time.perf_counter()
+                orc.sttran_forward(entry, sd)
+                runs.append(time.perf_counter() - t0)
+        finally:
+            if ctx is not None:
+                ctx.restore_original_limits()
+        med = float(np.median(runs)) if runs else first
+        if best is None or med < best[0]:
+            best = (med, nthr, max(len(runs), 1))
+    med, nthr, nruns = best
+    return {"value": T / med, "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"{nruns} forward(s) of one {T}x{N} clip, numpy/BLAS fp32 oracle, best of 8/32/{ncpu} BLAS "
+                      f"threads, median {med:.3f} s/clip"}
 
 
 def main():

@@ -56,7 +56,7 @@ def _sigmoid(x):
 
 
 def _cast(sd, dtype):
-    return {k: (v.astype(dtype) if v.dtype.kind == "f" else v) for k, v in sd.items()}
+    return {k: (v.astype(dtype, copy=False) if v.dtype.kind == "f" else v) for k, v in sd.items()}
 
 
 # ---------------------------------------------------------------------------------------
@@ -103,19 +103,26 @@ def _im2col(x, k, stride, pad, fill=0.0):
     return cols.reshape(P, C * k * k, Ho * Wo), Ho, Wo
 
 
+def _bmm_shared(w, x):
+    """w [M,K] @ x [P,K,N] -> [P,M,N] as ONE GEMM [M,K] x [K,P*N] (one BLAS call instead of P small ones)."""
+    P, K, N = x.shape
+    y = w @ np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(K, P * N)
+    return y.reshape(w.shape[0], P, N).transpose(1, 0, 2)
+
+
 def mask_conv_stack(masks, sd):
     """`self.conv` (lib/sttran.py:337-345): conv7x7/s2/p3 -> ReLU -> BN -> maxpool3/s2/p1
     -> conv3x3/p1 -> ReLU -> BN.  masks [P,2,27,27] -> [P,256,7,7]."""
     P = masks.shape[0]
     cols, Ho, Wo = _im2col(masks, 7, 2, 3)
     w0 = sd["conv.0.weight"].reshape(128, -1)
-    c1 = np.matmul(w0, cols) + sd["conv.0.bias"][None, :, None]           # [P,128,196]
+    c1 = _bmm_shared(w0, cols) + sd["conv.0.bias"][None, :, None]         # [P,128,196]
     c1 = _bn(np.maximum(c1, 0).reshape(P, 128, Ho, Wo), sd, "conv.2", 1)
     pc, Hp, Wp = _im2col(c1, 3, 2, 1, fill=-np.inf)                        # max-pool as im2col
     c2 = pc.reshape(P, 128, 9, Hp * Wp).max(axis=2).reshape(P, 128, Hp, Wp)
     cols2, H2, W2 = _im2col(c2, 3, 1, 1)
     w4 = sd["conv.4.weight"].reshape(256, -1)
-    c3 = np.matmul(w4, cols2) + sd["conv.4.bias"][None, :, None]
+    c3 = _bmm_shared(w4, cols2) + sd["conv.4.bias"][None, :, None]
     return _bn(np.maximum(c3, 0).reshape(P, 256, H2, W2), sd, "conv.6", 1)
 
 
@@ -131,7 +138,7 @@ def pair_fusion(entry, sd, pred_labels, chunk=256):
     for a in range(0, P, chunk):                                           # :386-387
         b = min(P, a + chunk)
         u = entry["union_feat"][a:b].astype(dt).reshape(b - a, wu.shape[1], 49)
-        y = np.matmul(wu, u) + sd["union_func1.bias"][None, :, None]       # 1x1 conv
+        y = _bmm_shared(wu, u) + sd["union_func1.bias"][None, :, None]     # 1x1 conv
         c3 = mask_conv_stack(entry["spatial_masks"][a:b].astype(dt), sd).reshape(b - a, 256, 49)
         vr[a:b] = _lin((y + c3).reshape(b - a, 256 * 49), sd["vr_fc.weight"], sd["vr_fc.bias"])
     e1 = sd["obj_embed.weight"][pred_labels[pi[:, 0]]]                     # :390-393
@@ -140,41 +147,52 @@ def pair_fusion(entry, sd, pred_labels, chunk=256):
 
 
 # ---------------------------------------------------------------------------------------
-# A2  multi-head attention on ONE unpadded sequence (torch nn.MultiheadAttention semantics)
+# A2  multi-head attention (torch nn.MultiheadAttention semantics).  The three projections and the
+#     output projection are row-wise, so they run over ALL tokens at once (as the reference does on
+#     its padded batch, lib/transformer.py:144,163); only softmax(QK^T)V is per sequence.
 # ---------------------------------------------------------------------------------------
-def mha(q_in, k_in, v_in, w_in, b_in, w_out, b_out, nhead=NHEAD):
-    d = q_in.shape[1]
+def _attend(q, k, v, seqs, nhead=NHEAD):
+    """q,k,v [tokens, d] already projected; seqs = list of (offset, length).  Returns [tokens, d]."""
+    d = q.shape[1]
     hd = d // nhead
+    scale = q.dtype.type(1.0 / np.sqrt(hd))
+    out = np.empty_like(q)
+    for o, n in seqs:
+        qs = q[o:o + n].reshape(n, nhead, hd).transpose(1, 0, 2) * scale
+        ks = k[o:o + n].reshape(n, nhead, hd).transpose(1, 0, 2)
+        vs = v[o:o + n].reshape(n, nhead, hd).transpose(1, 0, 2)
+        a = np.matmul(qs, ks.transpose(0, 2, 1))
+        a = a - a.max(axis=-1, keepdims=True)
+        a = np.exp(a)
+        a = a / a.sum(axis=-1, keepdims=True)
+        out[o:o + n] = np.matmul(a, vs).transpose(1, 0, 2).reshape(n, d)
+    return out
+
+
+def mha(q_in, k_in, v_in, w_in, b_in, w_out, b_out, seqs=None, nhead=NHEAD):
+    d = q_in.shape[1]
     q = _lin(q_in, w_in[:d], b_in[:d])
     k = _lin(k_in, w_in[d:2 * d], b_in[d:2 * d])
     v = _lin(v_in, w_in[2 * d:], b_in[2 * d:])
-    S = q.shape[0]
-    q = q.reshape(S, nhead, hd).transpose(1, 0, 2) * q.dtype.type(1.0 / np.sqrt(hd))
-    k = k.reshape(-1, nhead, hd).transpose(1, 0, 2)
-    v = v.reshape(-1, nhead, hd).transpose(1, 0, 2)
-    a = np.matmul(q, k.transpose(0, 2, 1))
-    a = a - a.max(axis=-1, keepdims=True)
-    a = np.exp(a)
-    a = a / a.sum(axis=-1, keepdims=True)
-    o = np.matmul(a, v).transpose(1, 0, 2).reshape(S, d)
+    o = _attend(q, k, v, seqs if seqs is not None else [(0, q.shape[0])], nhead)
     return _lin(o, w_out, b_out)
 
 
-def encoder_layer(x, sd, p):
+def encoder_layer(x, sd, p, seqs=None):
     """A3, `TransformerEncoderLayer.forward` lib/transformer.py:20-30 (post-norm, ReLU)."""
     a = mha(x, x, x, sd[p + ".self_attn.in_proj_weight"], sd[p + ".self_attn.in_proj_bias"],
-            sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"])
+            sd[p + ".self_attn.out_proj.weight"], sd[p + ".self_attn.out_proj.bias"], seqs)
     h = _ln(x + a, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
     f = _lin(np.maximum(_lin(h, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]), 0),
              sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
     return _ln(h + f, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
 
 
-def decoder_layer(g, pos, sd, p):
+def decoder_layer(g, pos, sd, p, seqs=None):
     """A4, `TransformerDecoderLayer.forward` lib/transformer.py:49-58: q = k = g+pos, v = g;
     LayerNorm after attention only."""
     a = mha(g + pos, g + pos, g, sd[p + ".multihead2.in_proj_weight"], sd[p + ".multihead2.in_proj_bias"],
-            sd[p + ".multihead2.out_proj.weight"], sd[p + ".multihead2.out_proj.bias"])
+            sd[p + ".multihead2.out_proj.weight"], sd[p + ".multihead2.out_proj.bias"], seqs)
     h = _ln(g + a, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])
     f = _lin(np.maximum(_lin(h, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]), 0),
              sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
@@ -198,37 +216,37 @@ def transformer(rel, counts, sd, enc_layers, dec_layers, stages=None):
     pre = "glocal_transformer."
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     T = len(counts)
-    local = np.empty_like(rel)
-    for t in range(T):                                                     # :144
-        if counts[t] == 0:
-            continue
-        x = rel[off[t]:off[t + 1]]
-        for i in range(enc_layers):
-            x = encoder_layer(x, sd, f"{pre}local_attention.layers.{i}")
-        local[off[t]:off[t + 1]] = x
+    frames = [(int(off[t]), int(counts[t])) for t in range(T) if counts[t] > 0]
+    local = rel
+    for i in range(enc_layers):                                            # :144
+        local = encoder_layer(local, sd, f"{pre}local_attention.layers.{i}", frames)
     if stages is not None:
         stages["local_output"] = local.copy()
     if T < 2:                                                              # transformer_wk.py:187-188
         return local
     pe = sd[pre + "position_embedding.weight"]
-    out = np.zeros_like(rel)
-    glayers = [np.empty((0, rel.shape[1]), dtype=rel.dtype) for _ in range(dec_layers)]
-    for j in range(T - 1):                                                 # :152-163
+    rows, slots, wins = [], [], []                                         # window tokens (:152-159)
+    for j in range(T - 1):
         n0, n1 = int(counts[j]), int(counts[j + 1])
-        if n0 + n1 == 0:
+        if n0 + n1 == 0:                                                   # transformer_wk.py:175-185
             continue
-        g = local[off[j]:off[j + 2]]
-        pos = np.concatenate([np.repeat(pe[0:1], n0, 0), np.repeat(pe[1:2], n1, 0)], axis=0)
-        for i in range(dec_layers):
-            g = decoder_layer(g, pos, sd, f"{pre}global_attention.layers.{i}")
-            if stages is not None:
-                glayers[i] = np.concatenate([glayers[i], g], axis=0)
+        wins.append((len(rows), n0 + n1, j, n0))
+        rows += list(range(off[j], off[j + 2]))
+        slots += [0] * n0 + [1] * n1
+    if not wins:
+        return local
+    g = local[np.asarray(rows)]
+    pos = pe[np.asarray(slots)]
+    seqs = [(o, n) for o, n, _, _ in wins]
+    for i in range(dec_layers):                                            # :163
+        g = decoder_layer(g, pos, sd, f"{pre}global_attention.layers.{i}", seqs)
+        if stages is not None:
+            stages[f"decoder_layer{i}"] = g.copy()
+    out = np.zeros_like(rel)
+    for o, n, j, n0 in wins:
         if j == 0:                                                         # :181-183
-            out[off[0]:off[1]] = g[:n0]
-        out[off[j + 1]:off[j + 2]] = g[n0:]                                # :185
-    if stages is not None:
-        for i in range(dec_layers):
-            stages[f"decoder_layer{i}"] = glayers[i]
+            out[off[0]:off[1]] = g[o:o + n0]
+        out[off[j + 1]:off[j + 2]] = g[o + n0:o + n]                       # :185
     return out
 
 
