@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--clips-per-step", type=int, default=0, help="0 = default for the workload")
     ap.add_argument("--model", default="sttran", choices=["sttran", "dsgdetr"],
                     help="dsgdetr = BASELINE.json configs[4]: lib/dsg_detr.py (sgdet branch) on the same kernels")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph (torch.cuda.CUDAGraph) and replay it: the forward only "
+                         "enqueues on the caller's stream, so it is capturable once the layout is cached")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -165,9 +168,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    run = step
+    if args.graph and world == 1:
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            step(); step()                              # warm every lazy path on the capture stream
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gpred = step()
+
+        def run():
+            graph.replay()
+            return gpred
+        run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pred = step()
+        pred = run()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -189,7 +207,7 @@ def main():
                                 f"(enc 1 / dec 3 layers, d=1936), inputs resident in HBM") if args.model == "sttran" else
                                (f"synthetic {T} frames x {N} boxes x 2048-d region features, DSG-DETR sgdet forward "
                                 f"(1 spatial + 3 temporal encoder layers, d=1936), inputs resident in HBM"),
-                   "clips_per_step": cps, "frames_per_clip": T, "boxes_per_frame": N, "pairs_per_step": P,
+                   "clips_per_step": cps, "hip_graph": bool(args.graph and world == 1), "frames_per_clip": T, "boxes_per_frame": N, "pairs_per_step": P,
                    "sharding": f"whole clips, {world} rank(s), RCCL all-gather of predictions" if world > 1
                                else "single GPU"},
     }
