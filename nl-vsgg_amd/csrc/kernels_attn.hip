@@ -330,7 +330,8 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
                        q_begin, out, dim, hd, scale, l16);
     return hipGetLastError();
   }
-  if (q_begin) return hipErrorInvalidValue;     // the long-sequence kernel computes every query row
+  // the long-sequence kernel computes every query row: q_begin is an optimisation hint only (rows before
+  // it are never read by the caller), so it is simply not used here
   const int skp = (max_len + 31) / 32 * 32;
   const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
   static int attr_max_long = 0;

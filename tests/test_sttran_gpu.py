@@ -245,3 +245,24 @@ def test_dsg_detr_oracle_larger_clip():
         np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
     with pytest.raises(NotImplementedError):
         DSG(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES)
+
+
+def test_long_sequences_use_general_attention(predcls, weights):
+    """frames with ~100 pairs: spatial sequences of 100 and temporal windows of 190 tokens go through the
+    query-tiled attention kernel (the short-sequence kernel stops at 80 keys); last-layer row pruning
+    then needs the general kernel to honour every query row."""
+    from oracle import sttran_oracle as orc
+    e = syn.make_entry(4242, [100, 90, 3])
+    ref = orc.sttran_forward(e, weights, dtype=np.float64)
+    pred = predcls(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
+
+
+def test_sequence_limit_is_an_error(predcls):
+    from nl_vsgg_amd._native import SttranError
+    e = syn.make_entry(4243, [300, 300])                  # a 600-token window exceeds the 480-key limit
+    with pytest.raises(SttranError) as ei:
+        predcls(_cuda_entry(e))
+    assert ei.value.code == 6                             # STTRAN_ERR_LIMIT
