@@ -266,3 +266,24 @@ def test_sequence_limit_is_an_error(predcls):
     with pytest.raises(SttranError) as ei:
         predcls(_cuda_entry(e))
     assert ei.value.code == 6                             # STTRAN_ERR_LIMIT
+
+
+@pytest.mark.parametrize("enc,dec", [(2, 1), (1, 2), (0, 3), (2, 0)])
+def test_other_layer_counts(enc, dec):
+    """enc_layer_num / dec_layer_num are constructor arguments (lib/sttran.py:316-318): the layer loops,
+    the first-layer de-duplication and the last-layer pruning must hold for any count."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.sttran import STTran
+    from oracle import sttran_oracle as orc
+    sd = syn.make_sttran_state_dict(11, enc_layers=enc, dec_layers=dec)
+    m = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES,
+               enc_layer_num=enc, dec_layer_num=dec, transformer_mode="wk", is_wks=True, feat_dim=2048).to("cuda:0")
+    rep = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    assert rep.missing_keys == []
+    e = syn.make_entry(500 + 10 * enc + dec, [3, 2, 0, 4, 1])
+    ref = orc.sttran_forward(e, sd, enc_layers=enc, dec_layers=dec, dtype=np.float64)
+    pred = m(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
