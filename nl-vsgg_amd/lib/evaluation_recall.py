@@ -44,35 +44,36 @@ def box_iou_plus1(box, boxes):
     return np.where((iw > 0) & (ih > 0), iou, 0.0)
 
 
-def _triplets(rels, classes, boxes):
-    """(class_s, predicate, class_o) rows and the 8-number (subject box | object box) rows."""
-    so = classes[rels[:, :2]]
-    trip = np.column_stack((so[:, 0], rels[:, 2], so[:, 1]))
-    tb = np.column_stack((boxes[rels[:, 0]], boxes[rels[:, 1]]))
-    return trip, tb
-
-
 def match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, pred_boxes, pred_classes, predicate_scores,
-                      obj_scores, iou_thresh=0.5):
+                      obj_scores, iou_thresh=0.5, iou_cache=None):
     """For every prediction (in descending order of subj_score * obj_score * predicate_score) the
     list of ground-truth relations it hits: equal class triple and both box IoUs >= iou_thresh
-    (`lib/evaluation_recall.py:630-695,731-773`)."""
+    (`lib/evaluation_recall.py:630-695,731-773`).
+
+    Vectorised: one [n_gt_rel, n_pred_rel] boolean matrix instead of the reference's per-GT Python loop.
+    `iou_cache` (optional dict) keeps the [n_gt_box, n_pred_box] IoU table of the frame, which is the
+    same for the three metrics computed on it."""
     if pred_rels.size == 0:
         return [[]]
-    gt_trip, gt_tb = _triplets(gt_rels, gt_classes, gt_boxes)
-    pr_trip, pr_tb = _triplets(pred_rels, pred_classes, pred_boxes)
     score = obj_scores[pred_rels[:, 0]] * obj_scores[pred_rels[:, 1]] * predicate_scores
     order = score.argsort()[::-1]                     # same primitive as the reference: ties resolve alike
-    pr_trip, pr_tb = pr_trip[order], pr_tb[order]
-    hits = [[] for _ in range(pr_trip.shape[0])]
-    same = (gt_trip[:, None, :] == pr_trip[None, :, :]).all(axis=2)      # [n_gt, n_pred]
-    for g in np.nonzero(same.any(axis=1))[0]:
-        cand = np.nonzero(same[g])[0]
-        gb = np.asarray(gt_tb[g], dtype=np.float32)    # the reference rounds through float32 here
-        pb = np.asarray(pr_tb[cand], dtype=np.float32)
-        ok = (box_iou_plus1(gb[:4], pb[:, :4]) >= iou_thresh) & (box_iou_plus1(gb[4:], pb[:, 4:]) >= iou_thresh)
-        for i in cand[ok]:
-            hits[i].append(int(g))
+    pr = pred_rels[order]
+    iou = None if iou_cache is None else iou_cache.get("iou")
+    if iou is None:
+        # the reference rounds the boxes through float32 before the float64 IoU (:757)
+        gb = np.asarray(gt_boxes, dtype=np.float32).astype(np.float64)
+        pb = np.asarray(pred_boxes, dtype=np.float32).astype(np.float64)
+        iou = np.stack([box_iou_plus1(g, pb) for g in gb]) if len(gb) else np.zeros((0, len(pb)))
+        if iou_cache is not None:
+            iou_cache["iou"] = iou
+    same = ((gt_classes[gt_rels[:, 0]][:, None] == pred_classes[pr[:, 0]][None, :])
+            & (gt_rels[:, 2][:, None] == pr[:, 2][None, :])
+            & (gt_classes[gt_rels[:, 1]][:, None] == pred_classes[pr[:, 1]][None, :]))
+    ok = (same & (iou[gt_rels[:, 0]][:, pr[:, 0]] >= iou_thresh) & (iou[gt_rels[:, 1]][:, pr[:, 1]] >= iou_thresh))
+    hits = [[] for _ in range(pr.shape[0])]
+    gi, pi = np.nonzero(ok)                           # row-major: ascending gt index within a prediction
+    for g, i in zip(gi.tolist(), pi.tolist()):
+        hits[i].append(g)
     return hits
 
 
@@ -166,9 +167,11 @@ class SceneGraphEvaluator:
         m, n_gt = self.mode, gt_rels.shape[0]
         assert n_gt != 0
 
+        cache = {}
+
         def run(pred_rels, pscore):
             return match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, boxes, classes, pscore, obj_scores,
-                                     self.iou_threshold)
+                                     self.iou_threshold, cache)
 
         # with graph constraint: one predicate (the arg-max) per row (:221-235)
         hits_c = run(np.column_stack((rels, scores.argmax(1))), scores.max(1))
@@ -182,15 +185,15 @@ class SceneGraphEvaluator:
         for k, (r, _) in _recall_at(hits_n, n_gt).items():
             self.result_dict[f"{m}_recall_nogc"][k].append(r)
         # semi constraint: arg-max for attention rows, every predicate above 0.5 for the others (:270-288)
-        s_rels, s_sc = [], []
-        for i in range(rels.shape[0]):
-            row = scores[i]
-            if row[0] + row[1] > 0:
-                s_rels.append(np.append(rels[i], row.argmax())); s_sc.append(row.max())
-            elif row[3] + row[4] > 0 or row[9] + row[10] > 0:
-                for kk in np.nonzero(row > 0.5)[0]:
-                    s_rels.append(np.append(rels[i], kk)); s_sc.append(row[kk])
-        hits_s = run(np.array(s_rels), np.array(s_sc))
+        is_att = (scores[:, 0] + scores[:, 1]) > 0
+        is_multi = ~is_att & (((scores[:, 3] + scores[:, 4]) > 0) | ((scores[:, 9] + scores[:, 10]) > 0))
+        over = (scores > 0.5) & is_multi[:, None]
+        over[is_att, :] = False
+        over[np.nonzero(is_att)[0], scores[is_att].argmax(1)] = True        # arg-max entry of attention rows
+        ri_s, ci_s = np.nonzero(over)                                          # row-major = the reference's order
+        s_rels = np.column_stack((rels[ri_s], ci_s)) if len(ri_s) else np.zeros((0, 3), dtype=rels.dtype)
+        s_sc = scores[ri_s, ci_s]
+        hits_s = run(s_rels, s_sc)
         for k, (r, _) in _recall_at(hits_s, n_gt).items():
             self.result_dict[f"{m}_semi_recall"][k].append(r)
         # per-predicate recall lists for the two mean-recall variants (:126-148); slot 0 also
