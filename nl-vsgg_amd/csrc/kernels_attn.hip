@@ -141,18 +141,18 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
 // two-frame-window sequences of a few dozen boxes): ONE workgroup per (sequence, head) stages K and V
 // once for all of the sequence's queries, on 16x16x4 MFMA tiles (16-row granularity: a 70-token
 // window pads to 80, not 96).
-//   phase 1  S = Q K^T : head_dim is processed in two 128-wide chunks so that Q and K chunks
-//            ([L16][132] each, row stride 132 dwords = conflict-free ds_read_b128) fit LDS together;
+//   phase 1  S = Q K^T : head_dim is processed in four 64-wide chunks so that Q and K chunks
+//            ([L16][68] each, row stride 68 dwords = conflict-free ds_read_b128) fit LDS together;
 //            each wave owns up to 7 score tiles whose accumulators persist across the chunks
 //   softmax  rows of S in LDS, wavefront shuffles, P written back normalised
-//   phase 2  O = P V   : V [L16][260] overwrites the Q/K region; wave w owns output columns
-//            [64w, 64w+64) for all query tiles (P rows as A operand via ds_read_b128, V as B operand via
+//   phase 2  O = P V   : V overwrites the Q/K region, one 128-column half at a time ([L16][132]); wave w
+//            owns columns [32w, 32w+32) of each half for all query tiles
+// LDS: 70 KB at 80 keys -> two workgroups per CU, so one stages while the other runs MFMAs. (P rows as A operand via ds_read_b128, V as B operand via
 //            conflict-free ds_read_b32)
 // q_begin (optional) = first query row of each sequence to compute: the last decoder layer only
 // needs the rows the 'latter' scatter reads (lib/transformer.py:179-185).
 // ------------------------------------------------------------------------------------------
 constexpr int kAttnShortMax = 80;
-constexpr int kChunk = 128, kCStride = kChunk + 4;      // 132 dwords: (132/4) odd -> distinct LDS slots
 constexpr int kShortTilesPerWave = 7;                   // ceil(5*5 / 4)
 
 template <int NCOLS_PAD>
@@ -181,6 +181,10 @@ __device__ __forceinline__ void stage_rows(float* dst, int dstride, const float*
   }
 }
 
+// CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2.  <64,128> needs 70 KB at
+// 80 keys (two workgroups per CU: long windows); <128,256> has half the barriers and is used while the
+// sequences are so short (<= 48 keys) that LDS does not limit residency anyway.
+template <int CHUNK, int VW>
 __global__ void __launch_bounds__(256)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
                        const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
@@ -197,10 +201,13 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   const int l15 = lane & 15, g = lane >> 4;
   const int Lk16 = (L + 15) & ~15, Lq16 = (Lq + 15) & ~15;
   const int nq = Lq16 >> 4, nk = Lk16 >> 4, ntiles = nq * nk;
-  const int region = max(2 * l16max * kCStride, l16max * kQStride);
-  float* Qc = smem;                          // [Lq16][132]
-  float* Kc = smem + l16max * kCStride;      // [Lk16][132]
-  float* Vs = smem;                          // [Lk16][260]   (phase 2, overwrites Qc/Kc)
+  constexpr int kChunk = CHUNK, kCStride = CHUNK + 4;   // 68 / 132 dwords: (stride/4) odd -> distinct LDS slots
+  constexpr int kVHalf = VW, kVStride = VW + 4;
+  constexpr int NVH = kHdPad / VW, DTW = VW / 64;       // V passes; 16-column tiles per wave per pass
+  const int region = max(2 * l16max * kCStride, l16max * kVStride);
+  float* Qc = smem;                          // [Lq16][CHUNK+4]
+  float* Kc = smem + l16max * kCStride;      // [Lk16][CHUNK+4]
+  float* Vs = smem;                          // [Lk16][VW+4]   (phase 2, overwrites Qc/Kc)
   float* Ps = smem + region;                 // [Lq16][Lk16 + 4]
   const int ps = Lk16 + 4;
   const int64_t ld = 3 * (int64_t)dim;
@@ -248,8 +255,8 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   }
   __syncthreads();
 
-  // ---- V into the (now free) Q/K region, overlapped with the softmax of other waves' rows -------
-  stage_rows<kHdPad>(Vs, kQStride, qp + 2 * dim, ld, Lk16, L, 0, hd, 1.f, tid);
+  // ---- softmax rows (wavefront shuffles), overlapped with staging the first V half -----------------
+  stage_rows<kVHalf>(Vs, kVStride, qp + 2 * dim, ld, Lk16, L, 0, hd, 1.f, tid);
   for (int r = wave; r < Lq16; r += 4) {
     float* pr = Ps + r * ps;
     float m = -INFINITY;
@@ -267,28 +274,36 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   }
   __syncthreads();
 
-  // ---- phase 2: O[q][d] = sum_key P[q][key] V[key][d]; wave owns d in [64w, 64w+64) -------------
+  // ---- phase 2: O[q][d] = sum_key P[q][key] V[key][d]; per V half, wave owns d in [32w, 32w+32) -------
   constexpr int kMaxQ = kAttnShortMax / 16;      // 5 query tiles
-  f32x4 o[kMaxQ][4];
+  f32x4 o[kMaxQ][4];                             // [query tile][pass*DTW + d-tile]
 #pragma unroll
   for (int qi = 0; qi < kMaxQ; ++qi)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[qi][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < nk; ++kb) {
-    float bv[4][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+  for (int vh = 0; vh < NVH; ++vh) {
+    if (vh) {
+      __syncthreads();                           // every wave is done with the first half
+      stage_rows<kVHalf>(Vs, kVStride, qp + 2 * dim, ld, Lk16, L, vh * kVHalf, hd, 1.f, tid);
+      __syncthreads();
+    }
+    for (int kb = 0; kb < nk; ++kb) {
+      float bv[DTW][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bv[dt][e] = Vs[(kb * 16 + 4 * g + e) * kQStride + wave * 64 + dt * 16 + l15];
+      for (int dt = 0; dt < DTW; ++dt)
 #pragma unroll
-    for (int qi = 0; qi < kMaxQ; ++qi) {
-      if (qi < nq) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + (qi * 16 + l15) * ps + kb * 16 + 4 * g);
+        for (int e = 0; e < 4; ++e) bv[dt][e] = Vs[(kb * 16 + 4 * g + e) * kVStride + wave * (16 * DTW) + dt * 16 + l15];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int qi = 0; qi < kMaxQ; ++qi) {
+        if (qi < nq) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + (qi * 16 + l15) * ps + kb * 16 + 4 * g);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv[dt][e], o[qi][dt], 0, 0, 0);
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int dt = 0; dt < DTW; ++dt)
+              o[qi][vh * DTW + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv[dt][e], o[qi][vh * DTW + dt], 0, 0, 0);
+        }
       }
     }
   }
@@ -298,7 +313,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
     if (qi < nq) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int d = wave * 64 + dt * 16 + l15;
+        const int d = (dt / DTW) * kVHalf + wave * (16 * DTW) + (dt % DTW) * 16 + l15;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = qi * 16 + 4 * g + e;
@@ -317,17 +332,20 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
   const float scale = 1.0f / sqrtf((float)hd);
   if (max_len <= kAttnShortMax) {
     const int l16 = (max_len + 15) & ~15;
-    const int region = std::max(2 * l16 * kCStride, l16 * kQStride);
+    const bool small = l16 <= 48;
+    const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
+    const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
-    static int attr_max = 0;
-    if (lds > attr_max) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_short_kernel),
+    static int attr_max[2] = {0, 0};
+    auto kern = small ? attention_short_kernel<128, 256> : attention_short_kernel<64, 128>;
+    if (lds > attr_max[small]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return e;
-      attr_max = lds;
+      attr_max[small] = lds;
     }
-    hipLaunchKernelGGL(attention_short_kernel, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len,
-                       q_begin, out, dim, hd, scale, l16);
+    hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, dim, hd,
+                       scale, l16);
     return hipGetLastError();
   }
   // the long-sequence kernel computes every query row: q_begin is an optimisation hint only (rows before
