@@ -423,11 +423,11 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < NP) load_piece(n);
+                if (n < NP && PIPE != 4 && PIPE != 5) load_piece(n);
                 ++n;
               }
 #pragma unroll
-          for (; n < NP; ++n) load_piece(n);       // tiles with fewer MFMAs per group than pieces
+          for (; n < NP; ++n) if (PIPE != 4 && PIPE != 5) load_piece(n);       // tiles with fewer MFMAs per group than pieces
           // one global load per MFMA gap (sched_group_barrier masks: 0x8 MFMA, 0x20 VMEM read)
 #pragma unroll
           for (int q = 0; q < NP && q < NM; ++q) {
@@ -449,11 +449,11 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < NP) store_piece(n, nxt);
+                if (n < NP && PIPE != 4 && PIPE != 5) store_piece(n, nxt);
                 ++n;
               }
 #pragma unroll
-          for (; n < NP; ++n) store_piece(n, nxt);
+          for (; n < NP; ++n) if (PIPE != 4 && PIPE != 5) store_piece(n, nxt);
           // one select + ds_write per MFMA gap (0x2 VALU, 0x200 DS write)
 #pragma unroll
           for (int q = 0; q < NP && q < NM; ++q) {
@@ -463,7 +463,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (PIPE != 3 && PIPE != 5) __syncthreads();     // PIPE 3/4/5: timing-only ablations (wrong results)
         read_frags(nxt, 0, fa0, fb0);
         mma(fa1, fb1);
       }

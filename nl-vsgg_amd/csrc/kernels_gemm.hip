@@ -127,6 +127,9 @@ static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, 
   const int pipe = v ? atoi(v) : STTRAN_GEMM_PIPE;
   if (pipe == 1) return launch_tile_p<T, Epi, 1>(s, tile_id, A, B, M, N, K, slab, epi);
   if (pipe == 2) return launch_tile_p<T, Epi, 2>(s, tile_id, A, B, M, N, K, slab, epi);
+  if (pipe == 3) return launch_tile_p<T, Epi, 3>(s, tile_id, A, B, M, N, K, slab, epi);
+  if (pipe == 4) return launch_tile_p<T, Epi, 4>(s, tile_id, A, B, M, N, K, slab, epi);
+  if (pipe == 5) return launch_tile_p<T, Epi, 5>(s, tile_id, A, B, M, N, K, slab, epi);
   return launch_tile_p<T, Epi, 0>(s, tile_id, A, B, M, N, K, slab, epi);
 #else
   return launch_tile_p<T, Epi, STTRAN_GEMM_PIPE>(s, tile_id, A, B, M, N, K, slab, epi);
