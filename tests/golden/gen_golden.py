@@ -34,6 +34,7 @@ CASES = {
     "two_frames":    (104, [2, 3], "predcls", True),
     "uniform_16x12": (105, [11] * 16, "predcls", False),
     "sgdet_ragged":  (106, [2, 4, 1, 3], "sgdet", True),
+    "uniform_64x36": (107, [35] * 64, "predcls", False),      # BASELINE.json configs[3] at full size
 }
 
 

@@ -44,6 +44,16 @@ def test_oracle_matches_reference(name, golden_dir, weights):
         np.testing.assert_allclose(stages["rel_features"][:4], g["rel_features_head"], atol=5e-5, rtol=0)
 
 
+@pytest.mark.skipif(os.environ.get("STTRAN_SLOW_TESTS") != "1", reason="~1 min and 2 GB: set STTRAN_SLOW_TESTS=1")
+def test_oracle_full_size_64x36(weights, golden_dir):
+    g = np.load(os.path.join(golden_dir, "sttran_uniform_64x36.npz"))
+    sd = _weights(weights, int(g["weight_seed"]))
+    entry = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist())
+    out = orc.sttran_forward(entry, sd)
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+        np.testing.assert_allclose(out[k], g[k], atol=5e-5, rtol=0, err_msg=k)
+
+
 def test_oracle_fp64_agrees_with_fp32(weights, golden_dir):
     g = np.load(os.path.join(golden_dir, "sttran_ragged_5.npz"))
     sd = _weights(weights, int(g["weight_seed"]))

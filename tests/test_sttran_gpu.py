@@ -71,6 +71,17 @@ def test_golden_predcls(name, hint, predcls, golden_dir):
     predcls.taps = False
 
 
+def test_golden_full_size_64x36(predcls, golden_dir):
+    """BASELINE.json configs[3] at its full size (2240 pairs, 4410 decoder tokens) against the reference's own
+    output on the same seeded clip (the reference CPU forward takes ~5 s; only its [P,26] result is stored)."""
+    g = np.load(os.path.join(golden_dir, "sttran_uniform_64x36.npz"))
+    e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist())
+    pred = predcls(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        np.testing.assert_allclose(pred[k].cpu().numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
+
+
 def test_golden_sgdet(sgdet, golden_dir):
     g = np.load(os.path.join(golden_dir, "sttran_sgdet_ragged.npz"))
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
