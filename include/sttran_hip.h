@@ -153,6 +153,48 @@ const char* sttran_version(void);
 int sttran_union_boxes_masks(const float* boxes, const int64_t* pair_idx, const float* im_idx, int64_t num_pairs,
                              int32_t pool, float* union_boxes, float* spatial_masks, void* stream);
 
+/* The step immediately after the path: Recall@K matching of one clip's predictions with
+ * its ground truth -- the per-frame core of `SceneGraphEvaluator.evaluate_scene_graph`
+ * (lib/evaluation_recall.py:397-465): candidate selection of the three metrics (:209-235 with graph
+ * constraint, :321-350 no constraint, :257-300 semi constraint), ordering by
+ * subj_score * obj_score * predicate_score (:630-695) and matching by class triple + two float64
+ * IoUs >= iou_threshold (:731-773, lib/fpn/box_intersections_cpu/bbox.pyx:21-61).
+ * All pointers are device pointers.  Predictions are sttran_forward's outputs (attention = logits, the
+ * softmax of :400 is applied here).  Ground truth is packed per clip: frame f owns ground-truth boxes
+ * gt_box_off[f]..gt_box_off[f+1] (box 0 = the person) and relations gt_rel_off[f]..gt_rel_off[f+1];
+ * gt_rels rows are (subject box, object box, predicate id) with box ids local to the frame.
+ * flags [num_gt_rels, 9] uint8: flags[g][3*m + k] = 1 when relation g is hit within the first
+ * {10, 20, 50}[k] predictions of metric m (0 with constraint, 1 no constraint, 2 semi constraint).
+ * status (int32, device, caller zeroes it): bit 0 = a frame has more pairs than sttran_eval_max_pairs(),
+ * bit 1 = pair_idx out of range; frames that set a bit get all-zero flags. */
+typedef struct SttranEvalInputs {
+  int32_t struct_size;
+  int32_t num_frames;            /* frames in the ground truth (frame ids 0..num_frames-1)        */
+  int32_t num_pairs;             /* P                                                              */
+  int32_t num_boxes;             /* B                                                              */
+  int32_t num_gt_rels;           /* rows of gt_rels / flags                                        */
+  int32_t attention_classes, spatial_classes, contact_classes;   /* 3, 6, 17                      */
+  int32_t im_idx_dtype;          /* STTRAN_DTYPE_F32 or STTRAN_DTYPE_I64                           */
+  int32_t reserved;
+  double iou_threshold;          /* 0.5 (tools/test_STTran.py:69)                                   */
+  const float* attention_logits; /* [P, attention_classes]                                         */
+  const float* spatial;          /* [P, spatial_classes]  probabilities                            */
+  const float* contacting;       /* [P, contact_classes]  probabilities                            */
+  const int64_t* pair_idx;       /* [P, 2]                                                         */
+  const void* im_idx;            /* [P] ascending frame id                                         */
+  const float* boxes;            /* [B, 5] col 0 = frame id                                        */
+  const int64_t* classes;        /* [B] labels (predcls) or pred_labels                            */
+  const float* obj_scores;       /* [B] scores (predcls) or pred_scores                            */
+  const int32_t* gt_box_off;     /* [num_frames + 1]                                               */
+  const float* gt_boxes;         /* [G, 4] x1,y1,x2,y2 (float32, as the reference rounds them :757) */
+  const int32_t* gt_classes;     /* [G]                                                            */
+  const int32_t* gt_rel_off;     /* [num_frames + 1]                                               */
+  const int32_t* gt_rels;        /* [num_gt_rels, 3]                                               */
+} SttranEvalInputs;
+int sttran_eval_recall(const SttranEvalInputs* in, uint8_t* flags, int32_t* status, void* stream);
+/* most pairs one frame may have for the given number of predicate columns (26 -> 96) */
+int32_t sttran_eval_max_pairs(int32_t num_predicates);
+
 /* profiling (no reference counterpart; SURVEY 5 "Tracing / profiling: none") */
 int sttran_profile_enable(SttranHandle* h, int32_t enable);
 int sttran_profile_reset(SttranHandle* h);

@@ -54,6 +54,18 @@ class SttranProfile(C.Structure):
                 ("bytes", C.c_double * PROF_CLASSES), ("launches", C.c_uint64 * PROF_CLASSES)]
 
 
+class SttranEvalInputs(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("num_frames", C.c_int32), ("num_pairs", C.c_int32),
+                ("num_boxes", C.c_int32), ("num_gt_rels", C.c_int32),
+                ("attention_classes", C.c_int32), ("spatial_classes", C.c_int32), ("contact_classes", C.c_int32),
+                ("im_idx_dtype", C.c_int32), ("reserved", C.c_int32), ("iou_threshold", C.c_double),
+                ("attention_logits", C.c_void_p), ("spatial", C.c_void_p), ("contacting", C.c_void_p),
+                ("pair_idx", C.c_void_p), ("im_idx", C.c_void_p), ("boxes", C.c_void_p),
+                ("classes", C.c_void_p), ("obj_scores", C.c_void_p),
+                ("gt_box_off", C.c_void_p), ("gt_boxes", C.c_void_p), ("gt_classes", C.c_void_p),
+                ("gt_rel_off", C.c_void_p), ("gt_rels", C.c_void_p)]
+
+
 # every symbol include/sttran_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("sttran_create", C.c_int, [C.POINTER(SttranConfig), C.POINTER(C.c_void_p)]),
@@ -72,6 +84,8 @@ SYMBOLS = [
     ("sttran_profile_read", C.c_int, [C.c_void_p, C.POINTER(SttranProfile)]),
     ("sttran_union_boxes_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    ("sttran_eval_recall", C.c_int, [C.POINTER(SttranEvalInputs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("sttran_eval_max_pairs", C.c_int32, [C.c_int32]),
     ("sttran_debug_gemm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("sttran_debug_mfma_peak", C.c_int, [C.c_int32, C.POINTER(C.c_double)]),

@@ -37,6 +37,18 @@ hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t 
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
                              int P, int K, float* slab);
 
+// Recall@K matching of one clip against its packed ground truth (lib/evaluation_recall.py:397-465,630-773):
+// flags[g][metric*3 + k] = ground-truth relation g is hit within the first {10,20,50} predictions of
+// metric {with constraint, no constraint, semi constraint}.  status: bit 0 = a frame has too many pairs,
+// bit 1 = pair_idx out of range.
+hipError_t launch_eval_recall(hipStream_t s, const float* att, const float* spa, const float* con,
+                              const int64_t* pair_idx, const void* im_idx, int im_idx_i64, const float* boxes,
+                              const int64_t* classes, const float* obj_scores, int P, int B, int na, int ns, int nc,
+                              int F, const int32_t* gt_box_off, const float* gt_boxes, const int32_t* gt_classes,
+                              const int32_t* gt_rel_off, const int32_t* gt_rels, double iou_thr, uint8_t* flags,
+                              int32_t* status);
+int eval_max_pairs_per_frame(int ncol);
+
 // union boxes + soft box masks of each pair (lib/object_detector.py:110-124)
 hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int64_t* pair_idx, const float* im_idx,
                                     int P, int pool, float* union_boxes, float* masks);

@@ -911,6 +911,31 @@ int sttran_union_boxes_masks(const float* boxes, const int64_t* pair_idx, const 
                                   union_boxes, spatial_masks) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+int sttran_eval_recall(const SttranEvalInputs* in, uint8_t* flags, int32_t* status, void* stream) {
+  if (!in || in->struct_size != (int32_t)sizeof(SttranEvalInputs) || !status) return STTRAN_ERR_INVALID;
+  if (in->num_frames < 0 || in->num_pairs < 0 || in->num_boxes < 0 || in->num_gt_rels < 0) return STTRAN_ERR_INVALID;
+  const int ncol = in->attention_classes + in->spatial_classes + in->contact_classes;
+  // the semi-constraint rule reads columns 0,1 / 3,4 / 9,10 (lib/evaluation_recall.py:270-276)
+  if (in->attention_classes < 2 || in->spatial_classes < 1 || in->contact_classes < 1 || ncol < 11 || ncol > 32)
+    return STTRAN_ERR_INVALID;
+  if (in->im_idx_dtype != STTRAN_DTYPE_F32 && in->im_idx_dtype != STTRAN_DTYPE_I64) return STTRAN_ERR_INVALID;
+  if (in->num_frames == 0 || in->num_gt_rels == 0) return STTRAN_OK;
+  if (!flags || !in->gt_box_off || !in->gt_boxes || !in->gt_classes || !in->gt_rel_off || !in->gt_rels)
+    return STTRAN_ERR_INVALID;
+  if (in->num_pairs > 0 && (!in->attention_logits || !in->spatial || !in->contacting || !in->pair_idx || !in->im_idx ||
+                            !in->boxes || !in->classes || !in->obj_scores))
+    return STTRAN_ERR_INVALID;
+  hipError_t err = launch_eval_recall(reinterpret_cast<hipStream_t>(stream), in->attention_logits, in->spatial,
+                                      in->contacting, in->pair_idx, in->im_idx, in->im_idx_dtype == STTRAN_DTYPE_I64,
+                                      in->boxes, in->classes, in->obj_scores, in->num_pairs, in->num_boxes,
+                                      in->attention_classes, in->spatial_classes, in->contact_classes, in->num_frames,
+                                      in->gt_box_off, in->gt_boxes, in->gt_classes, in->gt_rel_off, in->gt_rels,
+                                      in->iou_threshold, flags, status);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int32_t sttran_eval_max_pairs(int32_t num_predicates) { return eval_max_pairs_per_frame(num_predicates); }
+
 // ---- kernel-level test hooks -------------------------------------------------------------------
 int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, const float* bias,
                       const float* residual, float* C, int64_t M, int64_t N, int64_t K, int32_t relu,

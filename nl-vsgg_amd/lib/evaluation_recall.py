@@ -101,6 +101,7 @@ class SceneGraphEvaluator:
         self.AG_contacting_predicates = list(AG_contacting_predicates)
         self.semithreshold = semithreshold
         self.num_rel = len(self.AG_all_predicates)
+        self.hit_flags = None                  # set to [] to record, per frame, which GT relations were hit
         self._att_ix = [self.AG_all_predicates.index(p) for p in self.AG_attention_predicates]
         self._spa_ix = [self.AG_all_predicates.index(p) for p in self.AG_spatial_predicates]
         self._con_ix = [self.AG_all_predicates.index(p) for p in self.AG_contacting_predicates]
@@ -196,6 +197,12 @@ class SceneGraphEvaluator:
         hits_s = run(s_rels, s_sc)
         for k, (r, _) in _recall_at(hits_s, n_gt).items():
             self.result_dict[f"{m}_semi_recall"][k].append(r)
+        if self.hit_flags is not None:        # [n_gt, 9] table in the device evaluator's layout (tests)
+            fl = np.zeros((n_gt, 9), dtype=np.uint8)
+            for mi, hits in enumerate((hits_c, hits_n, hits_s)):
+                for ki, (_, got) in enumerate(_recall_at(hits, n_gt).values()):
+                    fl[got, 3 * mi + ki] = 1
+            self.hit_flags.append(fl)
         # per-predicate recall lists for the two mean-recall variants (:126-148); slot 0 also
         # receives the all-predicates count, as in the reference
         for name, hits in (("mean_recall", hits_c), ("ng_mean_recall", hits_n)):

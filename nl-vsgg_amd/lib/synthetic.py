@@ -239,12 +239,13 @@ def union_box_masks(pair_rois: np.ndarray, size: int = 27) -> np.ndarray:
 
 
 def make_entry(seed: int, pairs_per_frame, boxes_per_frame=None, mode: str = "predcls",
-               im_idx_dtype=np.float32, real_masks: bool = False) -> dict:
+               im_idx_dtype=np.float32, real_masks: bool = False, geometry_only: bool = False) -> dict:
     """One clip in the reference `entry` schema, as numpy arrays.
 
     pairs_per_frame: list, n_t = number of (person, object) pairs in frame t (may be 0).
     Frame t holds 1 person box followed by n_t object boxes (predcls layout,
     `lib/object_detector.py:57-141`); empty frames hold no boxes.
+    geometry_only: leave out `features`, `union_feat`, `spatial_masks` (what the evaluator never reads).
     """
     counts = [int(c) for c in pairs_per_frame]
     T = len(counts)
@@ -273,12 +274,15 @@ def make_entry(seed: int, pairs_per_frame, boxes_per_frame=None, mode: str = "pr
         "scores": np.ones(B, dtype=np.float32),
         "pair_idx": np.asarray(pair_idx, dtype=np.int64).reshape(P, 2),
         "im_idx": np.asarray(im_idx, dtype=im_idx_dtype),
-        "features": _n(seed, "entry.features", (B, FEAT_DIM)),
-        "union_feat": _n(seed, "entry.union_feat", (P, FEAT_DIM, 7, 7)),
         "num_frames": T,
         "frame_counts": np.asarray(counts, dtype=np.int32),
     }
-    if real_masks:
+    if not geometry_only:
+        entry["features"] = _n(seed, "entry.features", (B, FEAT_DIM))
+        entry["union_feat"] = _n(seed, "entry.union_feat", (P, FEAT_DIM, 7, 7))
+    if geometry_only:
+        pass
+    elif real_masks:
         pi = entry["pair_idx"]
         rois = np.concatenate([bx[pi[:, 0], 1:], bx[pi[:, 1], 1:]], axis=1)
         entry["spatial_masks"] = (union_box_masks(rois, 27) - np.float32(0.5)).astype(np.float32)

@@ -39,6 +39,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=16)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--evaluator", choices=("hip", "host"), default="hip",
+                    help="hip: per-frame matching on the GPU (sttran_eval_recall); host: the numpy evaluator")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,18 +78,26 @@ def main():
             off += sum(shapes[i])
     print(f"[rank {rank}] {len(mine)} clips, {frames} frames in {dt:.3f} s (incl. H2D of the synthetic features)")
     if rank == 0:
-        ev = SceneGraphEvaluator(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
-                                 AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
-                                 iou_threshold=0.5)
+        kw = dict(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
+                  AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
+                  iou_threshold=0.5)
+        if a.evaluator == "hip":
+            from nl_vsgg_amd.lib.evaluation_recall_hip import SceneGraphEvaluator_HIP
+            ev = SceneGraphEvaluator_HIP(**kw)
+        else:
+            ev = SceneGraphEvaluator(**kw)
         ev.register_container()
+        t0 = time.perf_counter()
         for i in range(a.clips):
-            e = entries.get(i) or syn.make_entry(a.seed + i, shapes[i], real_masks=True)
-            p = got[i].cpu()
+            e = entries.get(i) or syn.make_entry(a.seed + i, shapes[i], geometry_only=True)
+            p = got[i] if a.evaluator == "hip" else got[i].cpu()
             pred = {"attention_distribution": p[:, :3], "spatial_distribution": p[:, 3:9],
                     "contacting_distribution": p[:, 9:], "pair_idx": e["pair_idx"], "im_idx": e["im_idx"],
                     "boxes": e["boxes"], "labels": e["labels"], "scores": e["scores"]}
             ev.evaluate_scene_graph(syn.make_gt_annotation(10_000 + a.seed + i, e), pred)
         ev.calculate_mean_recall()
+        print(f"[rank 0] {a.evaluator} evaluator: {a.clips} clips in {time.perf_counter() - t0:.3f} s "
+              "(incl. building the synthetic ground truth)")
         ev.print_stats()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
