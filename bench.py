@@ -128,7 +128,6 @@ def main():
     cps = args.clips_per_step or (16 if args.workload == "16x12" else 1)
     if args.model == "dsgdetr":
         from nl_vsgg_amd.lib.dsg_detr import STTran as DSGDETR
-        cps = 1                                   # one clip per call (class sequences span the clip)
         sd = syn.make_dsg_detr_state_dict(7)
         model = DSGDETR(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
                         obj_classes=CLASSES).to(device)
@@ -143,15 +142,15 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     clips = [device_clip(T, N, gen, device) for _ in range(cps)]
     if args.model == "dsgdetr":                   # sgdet entry: detector boxes, class distribution, scores
-        c = clips[0]
-        B = c["features"].shape[0]
-        xy = torch.rand(B, 2, device=device, generator=gen) * 300
-        wh = torch.rand(B, 2, device=device, generator=gen) * 150 + 10
-        c["boxes"] = torch.cat([torch.arange(T, device=device).repeat_interleave(N)[:, None].float(), xy, xy + wh], 1)
-        c["distribution"] = torch.softmax(torch.randn(B, 36, device=device, generator=gen), 1)
-        c["scores"] = c["distribution"].max(1).values
-        c["im_idx"] = c["im_idx"].long()
-    batch = pack_clips(clips) if args.model == "sttran" else clips[0]
+        for c in clips:
+            B = c["features"].shape[0]
+            xy = torch.rand(B, 2, device=device, generator=gen) * 300
+            wh = torch.rand(B, 2, device=device, generator=gen) * 150 + 10
+            c["boxes"] = torch.cat([torch.arange(T, device=device).repeat_interleave(N)[:, None].float(), xy, xy + wh], 1)
+            c["distribution"] = torch.softmax(torch.randn(B, 36, device=device, generator=gen), 1)
+            c["scores"] = c["distribution"].max(1).values
+            c["im_idx"] = c["im_idx"].long()
+    batch = pack_clips(clips) if cps > 1 else clips[0]
     P = int(batch["pair_idx"].shape[0])
     model.reserve(P, int(batch["features"].shape[0]))
     gathered = torch.empty((world * P, 26), device=device) if world > 1 else None

@@ -362,8 +362,8 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
 // dense rank of the pair's subject box (one person box per frame) among the sequence's subjects.
 // Stored in the STTran slots: dec_off/dec_len = class sequences, dec_src = pair of each token,
 // need = PE row of each token, out_src = P + token of each pair.
-void build_layout_dsg(const std::vector<int32_t>& counts, int64_t P, const int64_t* pair_idx, const int64_t* labels,
-                      std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P,
+                      const int64_t* pair_idx, const int64_t* labels, std::vector<int32_t>& buf, SttranHandle::Layout& L) {
   const int T = (int)counts.size();
   std::vector<int32_t> enc_off, enc_len, cls_off, cls_len, tok_pair, tok_pos, out_src(P);
   L = SttranHandle::Layout();
@@ -372,8 +372,16 @@ void build_layout_dsg(const std::vector<int32_t>& counts, int64_t P, const int64
     if (counts[t] > 0) { enc_off.push_back((int32_t)o); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
     o += counts[t];
   }
-  std::map<int64_t, std::vector<int32_t>> by_class;
-  for (int64_t p = 0; p < P; ++p) by_class[labels[pair_idx[2 * p + 1]]].push_back((int32_t)p);
+  // one temporal sequence per (clip, object class): lib/dsg_detr.py:528-541 groups one clip's pairs by class
+  std::vector<int32_t> clip_of_frame;
+  for (size_t c = 0; c < clips.size(); ++c) clip_of_frame.insert(clip_of_frame.end(), (size_t)clips[c], (int32_t)c);
+  std::map<std::pair<int32_t, int64_t>, std::vector<int32_t>> by_class;
+  {
+    int64_t p = 0;
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < counts[t]; ++i, ++p)
+        by_class[std::make_pair(clip_of_frame[t], labels[pair_idx[2 * p + 1]])].push_back((int32_t)p);
+  }
   for (auto& kv : by_class) {
     const std::vector<int32_t>& pairs = kv.second;
     std::vector<int64_t> subj;
@@ -681,14 +689,13 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     if (is_dsg) {
       // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
       // second model on the shared kernels, not the latency path
-      if (in->num_clips != 1) return fail(h, STTRAN_ERR_INVALID, "forward: DSG-DETR takes one clip per call");
       std::vector<int64_t> hp((size_t)P * 2), hl((size_t)B);
       HIPCK(hipMemcpyAsync(hp.data(), in->pair_idx, hp.size() * 8, hipMemcpyDeviceToHost, s));
       HIPCK(hipMemcpyAsync(hl.data(), in->labels, hl.size() * 8, hipMemcpyDeviceToHost, s));
       HIPCK(hipStreamSynchronize(s));
       for (int64_t p = 0; p < 2 * P; ++p)
         if (hp[p] < 0 || hp[p] >= B) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx out of range");
-      build_layout_dsg(counts, P, hp.data(), hl.data(), buf, h->lay);
+      build_layout_dsg(counts, clips, P, hp.data(), hl.data(), buf, h->lay);
       for (size_t i = 0; i < (size_t)P; ++i)
         if (buf[h->lay.o_need + i] >= 400) return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence");
     } else {

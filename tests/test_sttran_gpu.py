@@ -258,6 +258,28 @@ def test_dsg_detr_oracle_larger_clip():
         DSG(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES)
 
 
+def test_dsg_detr_packed_clips_equal_single_clips():
+    """class sequences are built per (clip, class): clips packed into one pass give the single-clip results"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    sd = syn.make_dsg_detr_state_dict(7)
+    m = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    clips = [syn.make_entry(610 + i, c, mode="sgdet", im_idx_dtype=np.int64)
+             for i, c in enumerate([[2, 3, 1], [4, 4], [1, 2, 2, 2], [5] * 6])]
+    singles = []
+    for e in clips:
+        p = m(_cuda_entry(e))
+        singles.append({k: p[k].cpu().numpy() for k in OUT_KEYS + ("distribution",)})
+    packed = m(pack_clips([_cuda_entry(e) for e in clips]))
+    torch.cuda.synchronize()
+    for one, many in zip(singles, unpack_predictions(packed)):
+        for k in OUT_KEYS + ("distribution",):
+            np.testing.assert_allclose(many[k].cpu().numpy(), one[k], atol=2e-5, rtol=0, err_msg=k)
+
+
 def test_long_sequences_use_general_attention(predcls, weights):
     """frames with ~100 pairs: spatial sequences of 100 and temporal windows of 190 tokens go through the
     query-tiled attention kernel (the short-sequence kernel stops at 80 keys); last-layer row pruning
