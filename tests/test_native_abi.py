@@ -52,6 +52,24 @@ def test_struct_sizes(native):
     assert lib.sttran_create(C.byref(cfg), C.byref(h)) == 1      # STTRAN_ERR_INVALID, no GPU touched
 
 
+def test_eval_recall_argument_checks(native):
+    """sttran_eval_recall validates its struct before any HIP call (so this runs without a GPU)"""
+    lib = native.load()
+    assert C.sizeof(native.SttranEvalInputs) == 10 * 4 + 8 + 13 * 8
+    assert lib.sttran_eval_max_pairs(26) == 96
+    status = C.c_int32(0)
+    inp = native.SttranEvalInputs(struct_size=4)
+    assert lib.sttran_eval_recall(C.byref(inp), None, C.byref(status), None) == 1
+    inp = native.SttranEvalInputs(struct_size=C.sizeof(native.SttranEvalInputs), num_frames=1, num_pairs=1, num_boxes=2,
+                                  num_gt_rels=1, attention_classes=3, spatial_classes=2, contact_classes=2,
+                                  iou_threshold=0.5)
+    assert lib.sttran_eval_recall(C.byref(inp), None, C.byref(status), None) == 1      # fewer than 11 predicate columns
+    inp.spatial_classes, inp.contact_classes = 6, 17
+    assert lib.sttran_eval_recall(C.byref(inp), None, C.byref(status), None) == 1      # null buffers
+    inp.num_frames = 0
+    assert lib.sttran_eval_recall(C.byref(inp), None, C.byref(status), None) == 0      # nothing to do
+
+
 def test_missing_library_fails_loudly(native, monkeypatch):
     monkeypatch.setattr(native, "_lib", None)
     monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libsttran_hip.so")
