@@ -44,15 +44,12 @@ struct GemmOperand {
 // (245 columns, 95.7 % full); per K-step each pair contributes one contiguous [32][49] slab
 // (6 272 bytes), copied flat into LDS; fragments are read with ds_read_b32 (lanes = consecutive
 // hw: conflict-free) using the same k-permutation as the A side.
-// B_CONV1 / B_CONV2: implicit-GEMM convolutions of the mask branch (lib/sttran.py:338,342).  Row n of
-// the B operand is an output position (pair, oy, ox), column k = (ci, ky, kx) in the order of
-// `weight.view(Cout, -1)` for B_CONV1 and (ky, kx, ci) for B_CONV2 (its weights are permuted to match
+// B_CONV2: the 3x3 convolution of the mask branch (lib/sttran.py:342) as an implicit GEMM.  Row n of the B
+// operand is an output position (pair, oy, ox), column k = (ky, kx, ci) (the weights are permuted to match
 // when they are loaded); elements are gathered from the NCHW input on the fly (no im2col buffer).
-enum { B_KMAJOR = 0, B_UNION = 1, B_CONV1 = 2, B_CONV2 = 3 };
+// (The 7x7/2 convolution in front of it has its own kernel, kernels_maskconv.hip.)
+enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
-template <> struct ConvGeo<B_CONV1> {   // Conv2d(2, 128, kernel 7, stride 2, padding 3) on 27x27 -> 14x14
-  static constexpr int KH = 7, S = 2, PAD = 3, HI = 27, HO = 14, CIN = 2, KREAL = 98;
-};
 template <> struct ConvGeo<B_CONV2> {   // Conv2d(128, 256, kernel 3, padding 1) on 7x7 -> 7x7
   static constexpr int KH = 3, S = 1, PAD = 1, HI = 7, HO = 7, CIN = 128, KREAL = 1152;
 };
@@ -183,7 +180,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
-  constexpr bool CONV = T::BKIND == B_CONV1 || T::BKIND == B_CONV2;
+  constexpr bool CONV = T::BKIND == B_CONV2;
   using Geo = ConvGeo<T::BKIND>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -288,7 +285,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     auto load_piece = [&](int n) {
       if (n < AV) {
         ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
-      } else if constexpr (T::BKIND == B_CONV2) {
+      } else if constexpr (CONV) {
         // K is ordered (ky, kx, ci) for this conv (weights permuted to match at load time), so the four
         // k of a piece are four consecutive input channels at ONE tap: the tap and its bounds test are
         // wave-uniform per K-step (128 channels = 4 K-steps per tap), the loads are 49 floats apart
@@ -302,22 +299,6 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) rb[i][e] = src[ok ? e * Geo::HI * Geo::HI : 0];
         cm[i] = ok ? 0xF : 0;
-      } else if constexpr (CONV) {
-        // four consecutive k = (ci, ky, kx) of one output position: scalar gathers from the NCHW input,
-        // out-of-image / K-tail elements read a clamped address and are zeroed at the LDS write (cm)
-        const int i = n - AV;
-        int m = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = kb_src + e;
-          const int ci = k / (Geo::KH * Geo::KH), r = k - ci * (Geo::KH * Geo::KH);
-          const int ky = r / Geo::KH, kx = r - ky * Geo::KH;
-          const int iy = cy[i] + ky, ix = cx[i] + kx;
-          const bool ok = k < Geo::KREAL && k < k_end && (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
-          m |= ok ? (1 << e) : 0;
-          rb[i][e] = pb[i][ok ? (ci * Geo::HI + iy) * Geo::HI + ix : 0];
-        }
-        cm[i] = m;
       } else {
         rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);
       }

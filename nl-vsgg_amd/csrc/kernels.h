@@ -19,8 +19,6 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
                        const EpiLinear& epi, GemmPlan plan, float* slab);
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab);
-hipError_t launch_mask_conv1(hipStream_t s, const float* w0_padded, const float* masks, const EpiConvRelBn& epi,
-                             int P, float* slab);
 hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, const EpiConvRelBn& epi, int P,
                              float* slab);
 
@@ -31,8 +29,11 @@ hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks);
 hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int P, int B,
                             int num_classes, const float* emb1, const float* emb2, int emb_dim,
                             int* subj_idx, int* obj_idx, float* x, int ldx, int col_off, int* err_flag);
-// MaxPool2d(k3, s2, p1): c1 [P*128, 14, 14] -> c2 [P*128, 7, 7]   (lib/sttran.py:341)
-hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t planes);
+// Conv2d(2,128,k7,s2,p3) -> ReLU -> BN -> MaxPool(3,2,1) of the spatial masks in one kernel (lib/sttran.py:337-341):
+// masks [P,2,27,27] -> c2 [P,128,7,7].  w0p = conv.0.weight re-ordered to [128][13][2][4] (tap group, input
+// channel, tap in group; taps 49..51 zero).
+hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w0p, const float* bias,
+                                  const float* scale, const float* shift, float* c2, int P);
 // union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]   (V already holds the mask-conv branch)
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
                              int P, int K, float* slab);

@@ -48,42 +48,6 @@ hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_
 }
 
 // ------------------------------------------------------------------------------------------
-// MaxPool2d(kernel 3, stride 2, padding 1) on 14x14 planes -> 7x7 (lib/sttran.py:341); padding acts as
-// -inf.  A workgroup stages 32 contiguous planes in LDS with coalesced 16-byte loads and pools from there.
-// ------------------------------------------------------------------------------------------
-constexpr int kPoolPlanes = 32;     // planes per workgroup: 32 x 196 floats = 25 KB of LDS
-
-__global__ void __launch_bounds__(256)
-maxpool3s2_kernel(const float* __restrict__ c1, float* __restrict__ c2, int64_t planes) {
-  __shared__ __attribute__((aligned(16))) float t[kPoolPlanes * 196];
-  const int64_t p0 = (int64_t)blockIdx.x * kPoolPlanes;
-  const int np = (int)min((int64_t)kPoolPlanes, planes - p0);
-  const f32x4* src = reinterpret_cast<const f32x4*>(c1 + p0 * 196);      // 196 floats = 49 float4 per plane
-  for (int i = threadIdx.x; i < np * 49; i += 256) reinterpret_cast<f32x4*>(t)[i] = src[i];
-  __syncthreads();
-  for (int i = threadIdx.x; i < np * 49; i += 256) {
-    const int pl = i / 49, pp = i - pl * 49, py = pp / 7, px = pp - py * 7;
-    const float* s = t + pl * 196;
-    float m = -INFINITY;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int y = 2 * py + dy, x = 2 * px + dx;
-        if (y >= 0 && y < 14 && x >= 0 && x < 14) m = fmaxf(m, s[y * 14 + x]);
-      }
-    c2[p0 * 49 + i] = m;
-  }
-}
-
-hipError_t launch_maxpool3s2(hipStream_t s, const float* c1, float* c2, int64_t planes) {
-  if (planes <= 0) return hipSuccess;
-  const int blocks = (int)((planes + kPoolPlanes - 1) / kPoolPlanes);
-  hipLaunchKernelGGL(maxpool3s2_kernel, dim3(blocks), dim3(256), 0, s, c1, c2, planes);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
 // union_boxes_masks: the step right before the hot path (lib/object_detector.py:110-124), which the
 // reference does with a device->host copy, a Cython loop (lib/draw_rectangles/draw_rectangles.pyx:27-67)
 // and a host->device copy.  Per pair: the union box of subject and object, and the two soft box masks

@@ -11,7 +11,6 @@ using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
-using TConv1 = GemmTile<128, 128, 2, 2, B_CONV1>;   // conv7x7/s2 as implicit GEMM, M = 128 channels
 using TConv2 = GemmTile<128, 128, 2, 2, B_CONV2>;   // conv3x3 as implicit GEMM
 using TUnion = GemmTile<128, 256, 2, 4, B_UNION>;   // 8 waves, wave tile 64x64, B = NCHW union_feat slabs
 
@@ -168,14 +167,6 @@ hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, cons
   return launch_tile<TUnion, EpiUnion>(s, TILE_UNION, A, B, 256, groups * 256, K, slab, epi);
 }
 
-// Conv2d(2,128,k7,s2,p3) -> ReLU -> BN as implicit GEMM: A = conv.0.weight zero-padded to [128][128]
-// (K = 98 -> 128), B gathered from masks [P,2,27,27], output C1[p][c][196]
-hipError_t launch_mask_conv1(hipStream_t s, const float* w0_padded, const float* masks, const EpiConvRelBn& epi,
-                             int P, float* slab) {
-  GemmOperand A{w0_padded, 128, nullptr, 0};
-  GemmOperand B{masks, 0, nullptr, 0};
-  return launch_tile<TConv1, EpiConvRelBn>(s, TILE_128x128, A, B, 128, P * 196, 128, slab, epi);
-}
 // Conv2d(128,256,k3,p1) -> ReLU -> BN as implicit GEMM: A = conv.4.weight.view(256, 1152), B gathered
 // from C2 [P,128,7,7], output V[p][c][49]
 hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, const EpiConvRelBn& epi, int P,

@@ -1,0 +1,179 @@
+// kernels_maskconv.hip -- first half of the spatial-mask branch of the pair fusion in ONE kernel:
+//   Conv2d(2, 128, kernel 7, stride 2, padding 3) -> ReLU -> BatchNorm2d(128, eval) -> MaxPool2d(3, 2, 1)
+//   masks [P, 2, 27, 27] -> C2 [P, 128, 7, 7]                              (lib/sttran.py:337-341)
+// The 14x14x128 convolution output (100 KB per pair) never reaches HBM: a workgroup computes it for one
+// pair in MFMA accumulators, applies bias / ReLU / BN, pools through a small LDS buffer and stores the
+// 7x7x128 result (25 KB per pair).
+//
+// Per pair the convolution is a GEMM  [128 channels] x [K = 2 x 49 taps] x [196 positions]:
+//   * one wave owns 32 output channels and all 196 positions (7 MFMA 32x32 column blocks, 224 columns);
+//   * its weights stay in registers for the whole launch (13 groups of 4 k per lane-half = 52 VGPRs):
+//     K is ordered (tap, channel-of-the-lane-half), i.e. in every v_mfma_f32_32x32x2_f32 the lower 32
+//     lanes carry input channel 0 and the upper 32 lanes input channel 1 of the same tap;
+//   * the B operand is never materialised (no im2col): the pair's two 27x27 masks sit zero-padded to 33x33
+//     in LDS, and B[k][n] is a single ds_read_b32 at  lane_base(n, half) + tap_offset, where the tap offset
+//     is a compile-time immediate -- no address arithmetic and no bounds tests in the loop.
+// Compute-bound on the MFMA pipe (K is only 98): 364 MFMAs per wave per pair.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace sttran {
+namespace {
+
+constexpr int kMcW = 33;                     // 27 + 2 * 3 padding
+constexpr int kMcPlane = kMcW * kMcW;        // 1089 floats per padded input channel
+constexpr int kMcMask = 2 * kMcPlane;        // one pair
+constexpr int kMcGroups = 13;                // 52 taps (49 real) in groups of 4
+constexpr int kMcPoolCh = 8;                 // channels pooled per round and wave
+constexpr int kMcLdsFloats = 2 * kMcMask + 4 * kMcPoolCh * 196 + 3 * 128;
+
+// float offset of tap t inside a padded plane (taps 49..51 are padding: weight 0, any valid address)
+__host__ __device__ constexpr int tap_offset(int t) { return t < 49 ? (t / 7) * kMcW + (t % 7) : 0; }
+
+__global__ void __launch_bounds__(256, 2)
+mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict__ w0p, const float* __restrict__ bias,
+                       const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ c2, int P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  float* mbuf = lds;                                                   // [2][kMcMask], double-buffered
+  float* pool = lds + 2 * kMcMask + wave * (kMcPoolCh * 196);         // wave-private [8][196]
+  float* par = lds + 2 * kMcMask + 4 * kMcPoolCh * 196;               // bias | scale | shift, [3][128]
+
+  // weights of this lane: channel 32*wave + fr, k = (group, half, e)  (w0p is [128][104] in that order)
+  f32x4 a[kMcGroups];
+#pragma unroll
+  for (int g = 0; g < kMcGroups; ++g)
+    a[g] = *reinterpret_cast<const f32x4*>(w0p + (wave * 32 + fr) * (kMcGroups * 8) + g * 8 + fh * 4);
+  // B base offsets: column n = 32 j + fr is output position (n / 14, n % 14); its receptive field starts at
+  // padded row 2*oy, column 2*ox of the lane-half's input channel
+  int lb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int n = 32 * j + fr;
+    lb[j] = fh * kMcPlane + (n < 196 ? (n / 14) * 2 * kMcW + (n % 14) * 2 : 0);
+  }
+  // pooling map of this lane: output o = lane + 64 i of the round's 8 x 49 block
+  int pbase[7];
+  unsigned pmask = 0;                                                  // bit 2i: row above exists, bit 2i+1: column left exists
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int o = lane + 64 * i, oo = o < kMcPoolCh * 49 ? o : 0;
+    const int ch = oo / 49, pos = oo - ch * 49, py = pos / 7, px = pos - py * 7;
+    pbase[i] = ch * 196 + 2 * py * 14 + 2 * px;
+    pmask |= (py > 0 ? 1u : 0u) << (2 * i) | (px > 0 ? 1u : 0u) << (2 * i + 1);
+  }
+
+  for (int i = tid; i < 2 * kMcMask; i += 256) mbuf[i] = 0.f;          // the padding stays zero for good
+  for (int i = tid; i < 128; i += 256) { par[i] = bias[i]; par[128 + i] = scale[i]; par[256 + i] = shift[i]; }
+  __syncthreads();
+  auto mask_slot = [](int i) {                                         // element i of [2][27][27] -> padded offset
+    const int ci = i / 729, r = i - ci * 729, y = r / 27, x = r - y * 27;
+    return ci * kMcPlane + (y + 3) * kMcW + (x + 3);
+  };
+  int p = blockIdx.x;
+  if (p < P) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int i = tid + 256 * q;
+      if (i < 1458) mbuf[mask_slot(i)] = masks[(int64_t)p * 1458 + i];
+    }
+  }
+  __syncthreads();
+
+  for (int it = 0; p < P; p += gridDim.x, ++it) {
+    const float* cur = mbuf + (it & 1) * kMcMask;
+    float* nxt = mbuf + ((it + 1) & 1) * kMcMask;
+    const int pn = p + gridDim.x;
+    float pre[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int i = tid + 256 * q;
+      pre[q] = (pn < P && i < 1458) ? masks[(int64_t)pn * 1458 + i] : 0.f;
+    }
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < kMcGroups; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int off = tap_offset(g * 4 + e);
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][e], cur[lb[j] + off], acc[j], 0, 0, 0);
+      }
+
+    // bias -> ReLU -> BN, then 3x3/2 max pooling, 8 channels of this wave at a time.
+    // accumulator register 4q + r of column block j = channel 8q + r + 4*half, position 32j + fr
+    float* dst = c2 + ((int64_t)p * 128 + wave * 32) * 49;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float cb[4], cs[4], ct[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = wave * 32 + 8 * q + r + 4 * fh;
+        cb[r] = par[ch]; cs[r] = par[128 + ch]; ct[r] = par[256 + ch];
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int n = 32 * j + fr;
+        if (n < 196) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pool[(r + 4 * fh) * 196 + n] = fmaxf(acc[j][4 * q + r] + cb[r], 0.f) * cs[r] + ct[r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int o = lane + 64 * i;
+        if (o < kMcPoolCh * 49) {
+          const float* s = pool + pbase[i];
+          const bool up = (pmask >> (2 * i)) & 1u, left = (pmask >> (2 * i + 1)) & 1u;
+          float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[14], s[15]));
+          if (left) m = fmaxf(m, fmaxf(s[-1], s[13]));
+          if (up) m = fmaxf(m, fmaxf(s[-14], s[-13]));
+          if (up && left) m = fmaxf(m, s[-15]);
+          dst[q * (kMcPoolCh * 49) + o] = m;
+        }
+      }
+      __syncthreads();
+    }
+
+    if (pn < P) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int i = tid + 256 * q;
+        if (i < 1458) nxt[mask_slot(i)] = pre[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// w0p: conv.0.weight [128][2][7][7] re-ordered to [128][13 groups][2 channels][4 taps], taps 49..51 zero
+hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w0p, const float* bias,
+                                  const float* scale, const float* shift, float* c2, int P) {
+  if (P <= 0) return hipSuccess;
+  static bool configured = false;
+  constexpr int lds_bytes = kMcLdsFloats * 4;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_conv1_pool_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = std::min(P, 2 * std::max(ncu, 1));
+  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, w0p, bias, scale, shift, c2, P);
+  return hipGetLastError();
+}
+
+}  // namespace sttran

@@ -59,12 +59,12 @@ struct SttranHandle {
   // derived parameters
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
-  float *heads_w = nullptr, *heads_b = nullptr, *w0_padded = nullptr, *w4_perm = nullptr;
+  float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
   // workspace
   int64_t capP = 0, capB = 0;
-  DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, cols, slab, idx, zbuf, hobj, ebuf;
+  DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
   int* err_flag = nullptr;
   // index-map staging (pinned) + cache of the last layout
   static constexpr int kStages = 4;
@@ -282,7 +282,6 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   HIPCK(h->uni.ensure((size_t)(cp + tok) * D * 4));
   HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
   HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
-  HIPCK(h->cols.ensure((size_t)cp * 128 * 196 * 4));   // conv1 output [P,128,14,14]
   HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + (size_t)cp * 2 * 4 + 4096));
   if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
     HIPCK(h->zbuf.ensure((size_t)cb * (h->cfg.feat_dim + 328) * 4));
@@ -452,7 +451,7 @@ void sttran_destroy(SttranHandle* h) {
   hipDeviceSynchronize();
   for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
   for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
-                    &h->c2, &h->cols, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
+                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
     b->release();
   for (int i = 0; i < SttranHandle::kStages; ++i) {
     if (h->stage[i]) hipHostFree(h->stage[i]);
@@ -508,14 +507,14 @@ int sttran_finalize_weights(SttranHandle* h) {
   const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   // arena layout (floats)
-  size_t total = 2 * 128 + 2 * 256 + 128 * 128 + 256 * 1152 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  size_t total = 2 * 128 + 2 * 256 + 128 * 104 + 256 * 1152 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
   HIPCK(h->derived.ensure(total * 4));
   float* p = h->derived.as<float>();
   auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
   h->bn1_scale = take(128); h->bn1_shift = take(128);
   h->bn2_scale = take(256); h->bn2_shift = take(256);
   h->heads_w = take((size_t)nh * D); h->heads_b = take(64);
-  h->w0_padded = take(128 * 128);
+  h->w0_perm = take(128 * 104);
   h->w4_perm = take(256 * 1152);
   h->dec.resize(c.dec_layers);
   for (int i = 0; i < c.dec_layers; ++i) h->dec[i].posbias = take(4 * D);
@@ -545,9 +544,16 @@ int sttran_finalize_weights(SttranHandle* h) {
     if ((rc = bn("object_classifier.pos_embed.0", 4, h->oc_pos_scale, h->oc_pos_shift))) return rc;
     if ((rc = bn("object_classifier.decoder_lin.1", 1024, h->oc_bn_scale, h->oc_bn_shift))) return rc;
   }
-  // conv.0.weight.view(128, 98) zero-padded to [128][128]: 16-byte aligned K-major rows for the GEMM A side
-  HIPCK(hipMemset(h->w0_padded, 0, 128 * 128 * 4));
-  HIPCK(hipMemcpy2D(h->w0_padded, 128 * 4, W(h, "conv.0.weight"), 98 * 4, 98 * 4, 128, hipMemcpyDeviceToDevice));
+  // conv.0.weight [128][ci 2][tap 49] -> [128][group 13][ci 2][tap-in-group 4] (taps 49..51 zero): the K order
+  // of mask_conv1_pool_kernel, whose lane halves carry the two input channels
+  {
+    std::vector<float> w(128 * 98), wp(128 * 104, 0.f);
+    HIPCK(hipMemcpy(w.data(), W(h, "conv.0.weight"), w.size() * 4, hipMemcpyDeviceToHost));
+    for (int co = 0; co < 128; ++co)
+      for (int ci = 0; ci < 2; ++ci)
+        for (int t = 0; t < 49; ++t) wp[(size_t)co * 104 + (t / 4) * 8 + ci * 4 + (t % 4)] = w[(size_t)co * 98 + ci * 49 + t];
+    HIPCK(hipMemcpy(h->w0_perm, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+  }
   // conv.4.weight [256][ci 128][ky 3][kx 3] -> [256][(ky, kx)][ci]: the K order of the B_CONV2 loader
   {
     std::vector<float> w(256 * 1152), wp(256 * 1152);
@@ -765,15 +771,11 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                        epi_plain(X0 + 512, D, W(h, "obj_fc.bias"))))) return rc;
   {
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
-    float* C1 = h->cols.as<float>();                    // [P, 128, 14, 14]
-    EpiConvRelBn e1{C1, W(h, "conv.0.bias"), h->bn1_scale, h->bn1_shift, 128, 196};
     {
-      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 196));
-      HIPCK(launch_mask_conv1(s, h->w0_padded, in->spatial_masks, e1, (int)P, h->slab.as<float>()));
-    }
-    {
-      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 0, 4.0 * P * 128 * (196 + 49));
-      HIPCK(launch_maxpool3s2(s, C1, C2, P * 128));
+      // conv 7x7/2 -> ReLU -> BN -> max-pool in one kernel; the [P,128,14,14] intermediate stays on chip
+      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 49));
+      HIPCK(launch_mask_conv1_pool(s, in->spatial_masks, h->w0_perm, W(h, "conv.0.bias"), h->bn1_scale,
+                                   h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152));
