@@ -153,16 +153,30 @@ def main():
     batch = pack_clips(clips) if cps > 1 else clips[0]
     P = int(batch["pair_idx"].shape[0])
     model.reserve(P, int(batch["features"].shape[0]))
-    gathered = torch.empty((world * P, 26), device=device) if world > 1 else None
+    # per-clip predictions of every rank: one fixed-size RCCL all-gather per step, issued asynchronously into
+    # one of two buffers so that it runs on RCCL's stream under the next step's forward (it is waited for
+    # two steps later and, for the last steps, in barrier(): all of them finish inside the timed region)
+    gathered = [torch.empty((world * P, 26), device=device) for _ in range(2)] if world > 1 else None
+    inflight = [None, None]
+    turn = [0]
 
     def step():
         pred = model(batch)
-        if world > 1:     # per-clip predictions of every rank, one fixed-size RCCL all-gather
-            dist.all_gather_into_tensor(gathered, pack_predictions(pred))
+        if world > 1:
+            k = turn[0]
+            if inflight[k] is not None:
+                inflight[k][0].wait()
+            rows = pack_predictions(pred)
+            inflight[k] = (dist.all_gather_into_tensor(gathered[k], rows, async_op=True), rows)
+            turn[0] = k ^ 1
         return pred
 
     def barrier():
         if world > 1:
+            for k in range(2):
+                if inflight[k] is not None:
+                    inflight[k][0].wait()
+                    inflight[k] = None
             dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
