@@ -101,9 +101,9 @@ typedef struct SttranOutputs {
  * profiling is enabled (bench.py's roofline leg). */
 #define STTRAN_PROF_CLASSES 8
 enum {
-  STTRAN_PROF_GEMM = 0,       /* gemm_f32_mfma (all Linear layers, conv2 as implicit GEMM) */
+  STTRAN_PROF_GEMM = 0,       /* gemm_f32_mfma (all Linear layers, conv3x3 as implicit GEMM) */
   STTRAN_PROF_UNION_CONV = 1, /* union_func1 1x1 conv                                      */
-  STTRAN_PROF_MASK_CONV = 2,  /* conv stack stage 1 + pool, im2col                         */
+  STTRAN_PROF_MASK_CONV = 2,  /* conv7x7/2 -> ReLU -> BN -> max-pool of the spatial masks   */
   STTRAN_PROF_ATTENTION = 3,
   STTRAN_PROF_LAYERNORM = 4,
   STTRAN_PROF_INDEX = 5,      /* gather / scatter / embedding / split-K reduce             */
