@@ -280,6 +280,21 @@ def test_dsg_detr_packed_clips_equal_single_clips():
             np.testing.assert_allclose(many[k].cpu().numpy(), one[k], atol=2e-5, rtol=0, err_msg=k)
 
 
+def test_longest_action_genome_clip(predcls, weights):
+    """121 frames (the longest clip of the AG test split) with 0..6 pairs per frame: 120 windows,
+    empty frames and empty windows in between"""
+    from oracle import sttran_oracle as orc
+    rng = np.random.default_rng(121)
+    counts = [int(c) for c in rng.integers(0, 7, 121)]
+    counts[0], counts[-1] = 3, 2
+    e = syn.make_entry(121121, counts)
+    ref = orc.sttran_forward(e, weights, dtype=np.float64)
+    pred = predcls(_cuda_entry(e))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
+
+
 def test_long_sequences_use_general_attention(predcls, weights):
     """frames with ~100 pairs: spatial sequences of 100 and temporal windows of 190 tokens go through the
     query-tiled attention kernel (the short-sequence kernel stops at 80 keys); last-layer row pruning
