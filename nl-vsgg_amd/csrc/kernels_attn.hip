@@ -153,43 +153,47 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
 // needs the rows the 'latter' scatter reads (lib/transformer.py:179-185).
 // ------------------------------------------------------------------------------------------
 constexpr int kAttnShortMax = 80;
-constexpr int kShortTilesPerWave = 7;                   // ceil(5*5 / 4)
 
-template <int NCOLS_PAD>
-__device__ __forceinline__ void stage_rows(float* dst, int dstride, const float* __restrict__ src, int64_t ld,
-                                           int nrows_pad, int nrows_valid, int col0, int ncols_valid, float scale,
-                                           int tid) {
-  // dst[r][c] = scale * src[r][col0 + c] for r < nrows_valid, col0 + c < ncols_valid; zero elsewhere
-  // (c < NCOLS_PAD).  float2 granules (rows are 8-byte aligned: head_dim*4 = 968 bytes); 256 threads;
-  // eight independent loads in flight per thread before the first LDS write.
-  constexpr int HALF = NCOLS_PAD / 2, U = 8;
+// Staging of a [rows][NCOLS_PAD] block in two halves so that the global loads of the NEXT block can be in flight
+// while the MFMAs of the current one run: stage_load pulls this thread's float2 granules into registers (zero for
+// rows / columns outside the matrix), stage_store scales and writes them to LDS.  Rows are 8-byte aligned
+// (head_dim * 4 = 968 bytes); 256 threads; MAXU = most granules per thread (compile time: the arrays stay in VGPRs).
+template <int NCOLS_PAD, int MAXU>
+__device__ __forceinline__ void stage_load(f32x2 (&v)[MAXU], const float* __restrict__ src, int64_t ld, int nrows_pad,
+                                           int nrows_valid, int col0, int ncols_valid, int tid) {
+  constexpr int HALF = NCOLS_PAD / 2;
   const int total = nrows_pad * HALF;
-  for (int i0 = tid; i0 < total; i0 += 256 * U) {
-    f32x2 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
-      v[u] = f32x2{0.f, 0.f};
-      if (i < total && r < nrows_valid && col0 + c2 < ncols_valid)
-        v[u] = *reinterpret_cast<const f32x2*>(src + (int64_t)r * ld + col0 + c2);
-    }
+  for (int u = 0; u < MAXU; ++u) {
+    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
+    v[u] = f32x2{0.f, 0.f};
+    if (i < total && r < nrows_valid && col0 + c2 < ncols_valid)
+      v[u] = *reinterpret_cast<const f32x2*>(src + (int64_t)r * ld + col0 + c2);
+  }
+}
+template <int NCOLS_PAD, int MAXU>
+__device__ __forceinline__ void stage_store(float* dst, int dstride, const f32x2 (&v)[MAXU], int nrows_pad, float scale,
+                                            int tid) {
+  constexpr int HALF = NCOLS_PAD / 2;
+  const int total = nrows_pad * HALF;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
-      if (i < total) *reinterpret_cast<f32x2*>(dst + r * dstride + c2) = f32x2{v[u][0] * scale, v[u][1] * scale};
-    }
+  for (int u = 0; u < MAXU; ++u) {
+    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
+    if (i < total) *reinterpret_cast<f32x2*>(dst + r * dstride + c2) = f32x2{v[u][0] * scale, v[u][1] * scale};
   }
 }
 
 // CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2.  <64,128> needs 70 KB at
 // 80 keys (two workgroups per CU: long windows); <128,256> has half the barriers and is used while the
 // sequences are so short (<= 48 keys) that LDS does not limit residency anyway.
-template <int CHUNK, int VW>
-__global__ void __launch_bounds__(256)
+template <int CHUNK, int VW, int MAXROWS, int MINWG>
+__global__ void __launch_bounds__(256, MINWG)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
                        const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
                        int dim, int hd, float scale, int l16max) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kMaxQ = MAXROWS / 16;                   // query (and key) tiles of 16 rows
+  constexpr int TPW = (kMaxQ * kMaxQ + 3) / 4;          // score tiles per wave
   const int s = blockIdx.y, h = blockIdx.x;
   const int L = seq_len[s];
   if (L <= 0) return;
@@ -213,17 +217,34 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   const int64_t ld = 3 * (int64_t)dim;
   const float* qp = qkv + (int64_t)base * ld + h * hd;
 
-  // ---- phase 1 --------------------------------------------------------------------------------
-  f32x4 acc[kShortTilesPerWave];
+  // ---- phase 1: S = (Q * scale) K^T over head-dim chunks.  The global loads of chunk c+1 (and, behind the last
+  //      chunk, of the first V block) are issued before the MFMAs of chunk c and written to LDS after them, so
+  //      only the very first load latency of a workgroup is exposed.
+  constexpr int NCH = kHdPad / kChunk;
+  constexpr int UQ = (MAXROWS * (kChunk / 2) + 255) / 256;      // float2 granules per thread of a Q or K chunk
+  constexpr int UV = (MAXROWS * (kVHalf / 2) + 255) / 256;      // ... of a V block
+  const float* vp = qp + 2 * dim;
+  f32x4 acc[TPW];
 #pragma unroll
-  for (int t = 0; t < kShortTilesPerWave; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < kHdPad; c0 += kChunk) {
-    if (c0) __syncthreads();
-    stage_rows<kChunk>(Qc, kCStride, qp + (int64_t)qb * ld, ld, Lq16, Lq, c0, hd, scale, tid);
-    stage_rows<kChunk>(Kc, kCStride, qp + dim, ld, Lk16, L, c0, hd, 1.f, tid);
+  for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 rq[UQ], rk[UQ], rv[UV];
+  stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
+  stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, 0, hd, tid);
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci) {
+    if (ci) __syncthreads();                      // every wave is done reading the previous chunk
+    stage_store<kChunk, UQ>(Qc, kCStride, rq, Lq16, scale, tid);
+    stage_store<kChunk, UQ>(Kc, kCStride, rk, Lk16, 1.f, tid);
     __syncthreads();
+    if (ci + 1 < NCH) {
+      stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, (ci + 1) * kChunk, hd, tid);
+      stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, (ci + 1) * kChunk, hd, tid);
+    } else {
+      stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of the MFMAs
 #pragma unroll
-    for (int t = 0; t < kShortTilesPerWave; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       const int tile = wave + 4 * t;
       if (tile < ntiles) {
         const int qi = tile / nk, kj = tile - qi * nk;
@@ -245,7 +266,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   }
   // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
 #pragma unroll
-  for (int t = 0; t < kShortTilesPerWave; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     const int tile = wave + 4 * t;
     if (tile < ntiles) {
       const int qi = tile / nk, kj = tile - qi * nk;
@@ -255,8 +276,9 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   }
   __syncthreads();
 
-  // ---- softmax rows (wavefront shuffles), overlapped with staging the first V half -----------------
-  stage_rows<kVHalf>(Vs, kVStride, qp + 2 * dim, ld, Lk16, L, 0, hd, 1.f, tid);
+  // ---- softmax rows (wavefront shuffles); the first V block (already in registers) goes to LDS first ------
+  stage_store<kVHalf, UV>(Vs, kVStride, rv, Lk16, 1.f, tid);
+  if (NVH > 1) stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, kVHalf, hd, tid);     // second block: lands during softmax + PV
   for (int r = wave; r < Lq16; r += 4) {
     float* pr = Ps + r * ps;
     float m = -INFINITY;
@@ -275,7 +297,6 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   __syncthreads();
 
   // ---- phase 2: O[q][d] = sum_key P[q][key] V[key][d]; per V half, wave owns d in [32w, 32w+32) -------
-  constexpr int kMaxQ = kAttnShortMax / 16;      // 5 query tiles
   f32x4 o[kMaxQ][4];                             // [query tile][pass*DTW + d-tile]
 #pragma unroll
   for (int qi = 0; qi < kMaxQ; ++qi)
@@ -284,8 +305,9 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
 #pragma unroll
   for (int vh = 0; vh < NVH; ++vh) {
     if (vh) {
-      __syncthreads();                           // every wave is done with the first half
-      stage_rows<kVHalf>(Vs, kVStride, qp + 2 * dim, ld, Lk16, L, vh * kVHalf, hd, 1.f, tid);
+      __syncthreads();                           // every wave is done with the previous block
+      stage_store<kVHalf, UV>(Vs, kVStride, rv, Lk16, 1.f, tid);
+      if (vh + 1 < NVH) stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, (vh + 1) * kVHalf, hd, tid);
       __syncthreads();
     }
     for (int kb = 0; kb < nk; ++kb) {
@@ -337,7 +359,7 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
     const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
     static int attr_max[2] = {0, 0};
-    auto kern = small ? attention_short_kernel<128, 256> : attention_short_kernel<64, 128>;
+    auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
     if (lds > attr_max[small]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
