@@ -319,6 +319,16 @@ def main():
             "per_class_tflops": {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in prof.items()
                                  if isinstance(v, dict) and v["ms"] > 0 and v["flops"] > 0},
         }
+    if args.model == "sttran":
+        # the whole forward against the MFMA ceiling of the REFERENCE's arithmetic (what lib/sttran.py
+        # executes per clip, before this implementation's de-duplication / dead-row elimination)
+        n, Pc = N - 1, T * (N - 1)
+        dec_tok = 2 * n * (T - 1)
+        flop_clip = (Pc * (102_238_208 + 45_844_480 + 100_672) + 3 * dec_tok * 45_844_480
+                     + Pc * 7_744 * n + 3 * dec_tok * 7_744 * 2 * n)
+        eq = result["value"] / world * (flop_clip / T) / 1e12
+        result["reference_arithmetic"] = {"gflop_per_frame": flop_clip / T / 1e9, "tflops_equivalent_per_gpu": eq,
+                                          "frac_of_fp32_mfma_peak": eq / FP32_MFMA_PEAK_TFLOPS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "sttran":
         result["cpu_baseline"] = cpu_baseline(T, N, sd)
     if rank == 0:
