@@ -11,7 +11,7 @@ using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
-using TConv2 = GemmTile<128, 128, 2, 2, B_CONV2>;   // conv3x3 as implicit GEMM
+using TConv2 = GemmTile<256, 128, 4, 2, B_CONV2>;   // conv3x3 as implicit GEMM: all 256 output channels in one tile (B gathered once)
 using TUnion = GemmTile<128, 256, 2, 4, B_UNION>;   // 8 waves, wave tile 64x64, B = NCHW union_feat slabs
 
 struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
@@ -173,7 +173,7 @@ hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, co
                              float* slab) {
   GemmOperand A{w4, 1152, nullptr, 0};
   GemmOperand B{c2, 0, nullptr, 0};
-  return launch_tile<TConv2, EpiConvRelBn>(s, TILE_128x128, A, B, 256, P * 49, 1152, slab, epi);
+  return launch_tile<TConv2, EpiConvRelBn>(s, TILE_256x128, A, B, 256, P * 49, 1152, slab, epi);
 }
 
 // ---- calibration: back-to-back v_mfma_f32_32x32x2_f32 on independent accumulators, no memory ----
