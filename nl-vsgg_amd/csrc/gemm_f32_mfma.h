@@ -46,7 +46,8 @@ struct GemmOperand {
 // hw: conflict-free) using the same k-permutation as the A side.
 // B_CONV2: the 3x3 convolution of the mask branch (lib/sttran.py:342) as an implicit GEMM.  Row n of the B
 // operand is an output position (pair, oy, ox), column k = (ky, kx, ci) (the weights are permuted to match
-// when they are loaded); elements are gathered from the NCHW input on the fly (no im2col buffer).
+// when they are loaded); elements are gathered from the channel-last input [pair][7][7][128] on the fly (no
+// im2col buffer).
 // (The 7x7/2 convolution in front of it has its own kernel, kernels_maskconv.hip.)
 enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
@@ -286,18 +287,17 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       if (n < AV) {
         ra[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka);
       } else if constexpr (CONV) {
-        // K is ordered (ky, kx, ci) for this conv (weights permuted to match at load time), so the four
-        // k of a piece are four consecutive input channels at ONE tap: the tap and its bounds test are
-        // wave-uniform per K-step (128 channels = 4 K-steps per tap), the loads are 49 floats apart
+        // K is ordered (ky, kx, ci) for this conv (weights permuted to match at load time) and the input is
+        // channel-last [pair][iy][ix][ci], so the four k of a piece are four consecutive input channels at ONE
+        // tap = one 16-byte load; the tap and its bounds test are wave-uniform per K-step (128 channels = 4
+        // K-steps per tap)
         const int i = n - AV;
         const int k0 = kb_src - kq4;                       // uniform
         const int tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH;
         const int ci = k0 - tap * Geo::CIN + kq4;
         const int iy = cy[i] + ky, ix = cx[i] + kx;
         const bool ok = k0 < k_end && (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
-        const float* src = pb[i] + (ok ? (ci * Geo::HI + iy) * Geo::HI + ix : 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rb[i][e] = src[ok ? e * Geo::HI * Geo::HI : 0];
+        rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci : 0));
         cm[i] = ok ? 0xF : 0;
       } else {
         rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);

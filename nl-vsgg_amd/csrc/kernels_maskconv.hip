@@ -1,9 +1,9 @@
 // kernels_maskconv.hip -- first half of the spatial-mask branch of the pair fusion in ONE kernel:
 //   Conv2d(2, 128, kernel 7, stride 2, padding 3) -> ReLU -> BatchNorm2d(128, eval) -> MaxPool2d(3, 2, 1)
-//   masks [P, 2, 27, 27] -> C2 [P, 128, 7, 7]                              (lib/sttran.py:337-341)
+//   masks [P, 2, 27, 27] -> C2 [P, 7, 7, 128] (channel-last)              (lib/sttran.py:337-341)
 // The 14x14x128 convolution output (100 KB per pair) never reaches HBM: a workgroup computes it for one
 // pair in MFMA accumulators, applies bias / ReLU / BN, pools through a small LDS buffer and stores the
-// 7x7x128 result (25 KB per pair).
+// 7x7x128 result (25 KB per pair), channel-last: the layout the implicit-GEMM 3x3 convolution gathers best.
 //
 // Per pair the convolution is a GEMM  [128 channels] x [K = 2 x 49 taps] x [196 positions]:
 //   * one wave owns 32 output channels and all 196 positions (7 MFMA 32x32 column blocks, 224 columns);
@@ -53,14 +53,16 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
     const int n = 32 * j + fr;
     lb[j] = fh * kMcPlane + (n < 196 ? (n / 14) * 2 * kMcW + (n % 14) * 2 : 0);
   }
-  // pooling map of this lane: output o = lane + 64 i of the round's 8 x 49 block
-  int pbase[7];
+  // pooling map of this lane: output o = lane + 64 i of the round's 49 x 8 block, channel fastest (the result is
+  // stored channel-last, [pair][7][7][128], so that the 3x3 convolution behind it gathers 4 channels per load)
+  int pbase[7], pdst[7];
   unsigned pmask = 0;                                                  // bit 2i: row above exists, bit 2i+1: column left exists
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int o = lane + 64 * i, oo = o < kMcPoolCh * 49 ? o : 0;
-    const int ch = oo / 49, pos = oo - ch * 49, py = pos / 7, px = pos - py * 7;
+    const int pos = oo / kMcPoolCh, ch = oo - pos * kMcPoolCh, py = pos / 7, px = pos - py * 7;
     pbase[i] = ch * 196 + 2 * py * 14 + 2 * px;
+    pdst[i] = pos * 128 + ch;
     pmask |= (py > 0 ? 1u : 0u) << (2 * i) | (px > 0 ? 1u : 0u) << (2 * i + 1);
   }
 
@@ -109,7 +111,7 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
 
     // bias -> ReLU -> BN, then 3x3/2 max pooling, 8 channels of this wave at a time.
     // accumulator register 4q + r of column block j = channel 8q + r + 4*half, position 32j + fr
-    float* dst = c2 + ((int64_t)p * 128 + wave * 32) * 49;
+    float* dst = c2 + (int64_t)p * (49 * 128) + wave * 32;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float cb[4], cs[4], ct[4];
@@ -138,7 +140,7 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
           if (left) m = fmaxf(m, fmaxf(s[-1], s[13]));
           if (up) m = fmaxf(m, fmaxf(s[-14], s[-13]));
           if (up && left) m = fmaxf(m, s[-15]);
-          dst[q * (kMcPoolCh * 49) + o] = m;
+          dst[q * kMcPoolCh + pdst[i]] = m;
         }
       }
       __syncthreads();
