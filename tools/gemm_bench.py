@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--pipes", default="0", help="main-loop variants (library built with EXTRA=-DSTTRAN_GEMM_EXPERIMENT)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--zeros", action="store_true", help="zero operands: separates clock (power) limits from schedule limits")
+    ap.add_argument("--cold", action="store_true",
+                    help="overwrite a 768 MB buffer before every timed launch (operands come from HBM, not from the "
+                         "256 MB Infinity Cache a back-to-back replay keeps warm); each launch timed on its own")
     a = ap.parse_args()
     lib = _native.load()
     p = lambda t: C.c_void_p(t.data_ptr())
@@ -47,6 +50,7 @@ def main():
     for _ in range(3):
         lib.sttran_debug_mfma_peak(20000, C.byref(pk))
     print(f"device fp32-MFMA rate (register-only loop): {pk.value:.1f} TFLOP/s (spec peak 157.3)")
+    flush = torch.zeros(192 * 1024 * 1024, device="cuda") if a.cold else None
     for name, M, N, K in SHAPES[a.shapes]:
         A = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda")
@@ -63,12 +67,22 @@ def main():
                     lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(a.iters):
-                    lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / a.iters
+                if a.cold:
+                    us = 0.0
+                    for _ in range(a.iters):
+                        flush.add_(1.0)
+                        e0.record()
+                        lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        us += e0.elapsed_time(e1) * 1e3 / a.iters
+                else:
+                    e0.record()
+                    for _ in range(a.iters):
+                        lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / a.iters
                 tf = 2.0 * M * N * K / us / 1e6
                 rows.append((tile, split, us, tf))
                 if tile and (best is None or us < best[2]):
