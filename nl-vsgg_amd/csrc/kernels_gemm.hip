@@ -61,11 +61,11 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
     const int cus = (int)std::min<int64_t>(G, num_cus());
     // cycles on one CU: its equal share of the (padded) MFMA steps at the tile's efficiency ...
     const double mfma = (double)tiles * ksteps / cus * ti.bm * ti.bn * kBK * 2.0 / 256.0 / ti.eff;
-    // ... plus parking and re-reading the partial tiles (~2 per workgroup) at ~2 KB/cycle chip-wide,
-    // the second launch, and the per-launch fixed cost
+    // ... plus parking and re-reading the partial tiles (~2 per workgroup) at ~4 KB/cycle chip-wide (they mostly
+    // stay in L2 / the Infinity Cache), the second launch, and the per-launch fixed cost
     const SkPlan sp = sk_plan(t, tiles, ksteps);
     const bool split = sp.tiles_sk != 0;
-    const double fix = split ? 2.0 * (sp.g_sk + sp.tiles_sk) * ti.bm * ti.bn * 4.0 / 2000.0 + 5000.0 : 0.0;
+    const double fix = split ? 2.0 * (sp.g_sk + sp.tiles_sk) * ti.bm * ti.bn * 4.0 / 4000.0 + 4000.0 : 0.0;
     const double time = mfma + fix + 6000.0;
     if (time < best_t) { best_t = time; best = {t, 1}; }
   }
