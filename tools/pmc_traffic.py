@@ -17,7 +17,7 @@ import pandas as pd
 
 CLASSES = [("gemm", r"gemm_sk_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)|gemm_fixup_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)"),
            ("union_conv", r"EpiUnion"), ("attention", r"attention"), ("layernorm", r"layernorm"),
-           ("mask_conv", r"maxpool"), ("index", r"pair_prep|gather_rows|objcls")]
+           ("mask_conv", r"mask_conv1_pool"), ("index", r"pair_prep|gather_rows|objcls")]
 
 
 def load(d, counter):
