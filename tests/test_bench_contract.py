@@ -1,0 +1,35 @@
+"""The bench line the driver parses: the committed end-of-round line (profiles/) must carry every field of the
+bench.py contract, and bench.py must still know the flags the driver passes."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r1_e_bench_default_with_cpu.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] < 1.0 and r["peak"] == 157.3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert abs(d["value"] - d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_accepts_the_driver_flags():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert re.search(rf'add_argument\("{flag}"', src), flag
+    assert 'dist.all_reduce(t, op=dist.ReduceOp.MAX)' in src          # max over ranks
+    assert src.count("barrier()") >= 3                                  # both sides of the timed region
