@@ -138,6 +138,7 @@ struct GemmTile {
   static constexpr int STAGE_B = BKIND == B_UNION ? kUStageB : BN * kLdsStride;
   static constexpr int STAGE = BM * kLdsStride + STAGE_B;              // floats per LDS stage
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static constexpr int GROUP_N = BKIND == B_UNION ? 1 : 8;            // tile_origin: N-tiles per group
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
   static_assert((BM * 8) % NT == 0, "A staging must divide evenly");
   static_assert(BKIND == B_UNION ? BN == 256 : (BN * 8) % NT == 0, "B staging must divide evenly");
@@ -148,6 +149,20 @@ struct GemmTile {
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+// Tile index -> (M-tile, N-tile).  Consecutive indices sweep GN N-tiles of one M-tile, then the next M-tile, so the
+// 32 workgroups of an XCD (consecutive indices, see xcd_remap) work on a compact ~4 x 8 block of tiles whose A and
+// B panels are shared through that XCD's L2, instead of one long column of M-tiles that streams all of A for every
+// N panel.  GN = 1 keeps the M-fastest order (union conv: the two M-tiles of a pair group stay adjacent).
+template <int GN>
+__device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+  if (GN <= 1) { tm = tile % tiles_m; tn = tile / tiles_m; return; }
+  const int per_group = tiles_m * GN;
+  const int g = tile / per_group, local = tile - g * per_group;
+  const int gn = min(GN, tiles_n - g * GN);
+  tm = local / gn;
+  tn = g * GN + (local - tm * gn);
 }
 
 // ---- stream-K schedule ------------------------------------------------------------------------
@@ -215,7 +230,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     int tile, ks0, ks1;
     const bool dp = dp_done < dp_per_wg;
     if (dp) {
-      tile = blk * dp_per_wg + dp_done;
+      tile = dp_done * G + blk;                   // at any moment the workgroups of an XCD hold consecutive tiles
       ks0 = 0; ks1 = ksteps;
       ++dp_done;
     } else {
@@ -225,8 +240,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       ks1 = min(ksteps, ks0 + (rg.end - it));
     }
     const int nsteps = ks1 - ks0;
-    const int m0 = (tile % tiles_m) * BM;          // consecutive tiles share the B panel
-    const int n0 = (tile / tiles_m) * BN;
+    int tile_m, tile_n;
+    tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int k_begin = ks0 * kBK;
     const int k_end = min(K, ks1 * kBK);
 
@@ -486,7 +502,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 // Tiles computed whole by one workgroup return at once.
 template <class T, class Epi>
 __global__ void __launch_bounds__(T::NT)
-gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
+gemm_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
                   const float* __restrict__ slab, Epi epi) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TN = T::TN;
   const int tile = blockIdx.x;                   // index inside the stream-K (leftover) region
@@ -520,7 +536,9 @@ gemm_fixup_kernel(int M, int N, int tiles_m, int ksteps, int g_sk, int sk_base, 
       for (int e = 0; e < 4; ++e) acc[e] += v[u][e];
   }
   const int gt = tiles_dp + tile;                // global tile index
-  const int m0 = (gt % tiles_m) * BM, n0 = (gt / tiles_m) * BN;
+  int tile_m, tile_n;
+  tile_origin<T::GROUP_N>(gt, tiles_m, tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int col = n0 + wn * (BN / T::WN) + j * 32 + fr;
   const int rbase = m0 + wm * (BM / T::WM) + i * 32 + 4 * fh + 8 * eq;   // e = 4*eq + r: row = r + 8*eq
 #pragma unroll

@@ -112,7 +112,7 @@ static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A
                      sp.g_sk, base, rem, slab, epi);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !split) return e;
-  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, ksteps,
+  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn, ksteps,
                      sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
   return hipGetLastError();
 }
