@@ -41,6 +41,24 @@ class PackedGroundTruth:
     def num_frames(self):
         return len(self.box_off) - 1
 
+    def to_annotation(self, evaluator):
+        """Back to the list-of-frames schema `evaluate_scene_graph` of the host evaluator / the reference takes."""
+        att, spa, con = evaluator._att_ix, evaluator._spa_ix, evaluator._con_ix
+        frames = []
+        for f in range(self.num_frames):
+            b0, b1 = int(self.box_off[f]), int(self.box_off[f + 1])
+            objs = [{"class": int(self.classes[b]), "bbox": self.boxes[b].copy(), "attention_relationship": [],
+                     "spatial_relationship": [], "contacting_relationship": []} for b in range(b0 + 1, b1)]
+            for s_, o_, p_ in self.rels[int(self.rel_off[f]):int(self.rel_off[f + 1])].tolist():
+                if p_ in spa and s_ != 0:
+                    objs[s_ - 1]["spatial_relationship"].append(spa.index(p_))
+                elif p_ in att:
+                    objs[o_ - 1]["attention_relationship"].append(att.index(p_))
+                else:
+                    objs[o_ - 1]["contacting_relationship"].append(con.index(p_))
+            frames.append([{"person_bbox": self.boxes[b0][None, :].copy()}] + objs)
+        return frames
+
     def on(self, device):
         key = str(device)
         if key not in self._dev:

@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Stand-in for BASELINE.json configs[2] ("full Action Genome test split, PredCls, 1 MI355X"): the real split's
+annotations, frames, VinVL features and checkpoint are not shipped with the reference, so this
+runs the whole inference loop of `tools/test_STTran.py:75-92` -- model, then evaluator -- over synthetic clips that
+have the REAL split's shape: 1 737 clips with the frames-per-clip of `datasets/AG/ag_test_id.pkl`
+(tests/golden/ag_test_clip_lengths.json: 54 371 frames, 3..121 per clip) and 1..6 pairs per frame.
+
+Per clip, on the device: random boxes / labels / region features / union features, `spatial_masks` from the boxes
+with the f-1 kernel (`union_boxes_and_masks`), ground truth = the same boxes with random relations.  Clips are
+packed 16 per forward (longest first); predictions go straight into the device evaluator (f-3).
+
+    python tools/ag_split_bench.py [--clips 1737] [--pack 16] [--evaluator hip|host|none]
+
+Prints one JSON line: frames/s of the loop (features resident in HBM when the clock starts) and the recall
+table of the (random-weight) model."""
+import argparse
+import gc
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+from nl_vsgg_amd.lib.evaluation_recall import SceneGraphEvaluator  # noqa: E402
+from nl_vsgg_amd.lib.evaluation_recall_hip import PackedGroundTruth, SceneGraphEvaluator_HIP  # noqa: E402
+from nl_vsgg_amd.lib.sttran import STTran, pack_clips, unpack_predictions  # noqa: E402
+from nl_vsgg_amd.lib.union_boxes import union_boxes_and_masks  # noqa: E402
+
+OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
+ATT = [f"att{i}" for i in range(3)]; SPA = [f"spa{i}" for i in range(6)]; CON = [f"con{i}" for i in range(17)]
+
+
+def make_clip(rng, gen, T, dev):
+    """One PredCls entry on the device + its packed ground truth (host arrays)."""
+    counts = rng.integers(1, 7, T).astype(np.int32)
+    B, P = int(T + counts.sum()), int(counts.sum())
+    frame_of_box = np.repeat(np.arange(T), counts + 1)
+    first = np.concatenate(([0], np.cumsum(counts + 1)[:-1]))             # the person box of each frame
+    labels = rng.integers(2, 37, B)
+    labels[first] = 1
+    xy = rng.uniform(0, 300, (B, 2)); wh = rng.uniform(10, 160, (B, 2))
+    boxes = np.concatenate([frame_of_box[:, None], xy, xy + wh], axis=1).astype(np.float32)
+    obj_rows = np.setdiff1d(np.arange(B), first)
+    pair_idx = np.stack([first[frame_of_box[obj_rows]], obj_rows], axis=1).astype(np.int64)
+    im_idx = frame_of_box[obj_rows].astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    entry = {"boxes": t(boxes), "labels": t(labels.astype(np.int64)), "scores": torch.ones(B, device=dev),
+             "pair_idx": t(pair_idx), "im_idx": t(im_idx), "frame_counts": counts, "num_frames": int(T),
+             "features": torch.randn(B, 2048, device=dev, generator=gen),
+             "union_feat": torch.randn(P, 2048, 7, 7, device=dev, generator=gen)}
+    _, entry["spatial_masks"] = union_boxes_and_masks(entry["boxes"], entry["pair_idx"], entry["im_idx"])
+    # ground truth: the detector boxes, one attention + 1..2 spatial + 1..2 contacting relations per object
+    rels, rel_off = [], [0]
+    for f in range(T):
+        for m in range(1, int(counts[f]) + 1):
+            rels.append((0, m, int(rng.integers(0, 3))))
+            for s in np.unique(rng.integers(0, 6, int(rng.integers(1, 3)))):
+                rels.append((m, 0, 3 + int(s)))
+            for c in np.unique(rng.integers(0, 17, int(rng.integers(1, 3)))):
+                rels.append((0, m, 9 + int(c)))
+        rel_off.append(len(rels))
+    box_off = np.concatenate(([0], np.cumsum(counts + 1)))
+    gt = PackedGroundTruth(box_off, boxes[:, 1:], labels, rel_off, np.asarray(rels))
+    return entry, gt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=1737)
+    ap.add_argument("--pack", type=int, default=16)
+    ap.add_argument("--evaluator", choices=("hip", "host", "none"), default="hip")
+    ap.add_argument("--hbm-budget-gb", type=float, default=180.0, help="clips resident at once (the rest in further passes)")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    with open(os.path.join(ROOT, "tests", "golden", "ag_test_clip_lengths.json")) as f:
+        lengths = json.load(f)["frames_per_clip"][:a.clips]
+    model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=OBJ,
+                   enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(dev)
+    model.eval()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()},
+                          strict=False)
+    kw = dict(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON, AG_attention_predicates=ATT,
+              AG_spatial_predicates=SPA, AG_contacting_predicates=CON, iou_threshold=0.5)
+    ev = {"hip": SceneGraphEvaluator_HIP, "host": SceneGraphEvaluator}.get(a.evaluator, lambda **k: None)(**kw)
+    if ev is not None:
+        ev.register_container()
+    rng = np.random.default_rng(2024)
+    gen = torch.Generator(device=dev).manual_seed(2024)
+    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])          # longest first
+    frames = pairs = 0
+    elapsed = 0.0
+    pos = 0
+    while pos < len(order):
+        # ---- build as many clips as the budget allows (untimed: the detector / feature store is out of scope) ----
+        chunk, used = [], 0.0
+        while pos < len(order) and used < a.hbm_budget_gb * 1e9:
+            e, gt = make_clip(rng, gen, lengths[order[pos]], dev)
+            used += e["union_feat"].numel() * 4 * 1.1
+            chunk.append((e, gt)); pos += 1
+        for _, gt in chunk:
+            if a.evaluator == "hip":
+                gt.on(dev)
+            elif a.evaluator == "host":
+                gt.annotation = gt.to_annotation(ev)
+        warm = model(pack_clips([dict(c[0]) for c in chunk[:2]])); del warm
+        gc.collect(); gc.freeze()
+        torch.cuda.synchronize()
+        # ---- the timed loop: forward over packs of clips, predictions into the evaluator --------------------
+        t0 = time.perf_counter()
+        for i in range(0, len(chunk), a.pack):
+            group = chunk[i:i + a.pack]
+            preds = unpack_predictions(model(pack_clips([dict(c[0]) for c in group])))
+            if ev is not None:
+                for (e, gt), p in zip(group, preds):
+                    p.update(pair_idx=e["pair_idx"], im_idx=e["im_idx"], boxes=e["boxes"], labels=e["labels"], scores=e["scores"])
+                    ev.evaluate_scene_graph(gt if a.evaluator == "hip" else gt.annotation, p)
+        if ev is not None:
+            ev.calculate_mean_recall()                       # flushes the device evaluator
+        torch.cuda.synchronize()
+        elapsed += time.perf_counter() - t0
+        frames += sum(c[0]["num_frames"] for c in chunk)
+        pairs += sum(int(c[0]["pair_idx"].shape[0]) for c in chunk)
+        del chunk
+        gc.unfreeze(); gc.collect(); torch.cuda.empty_cache()
+    out = {"workload": "Action-Genome-test-split-shaped synthetic clips (frames per clip from ag_test_id.pkl, 1..6 pairs per "
+                       "frame), STTran PredCls + Recall@K evaluator, features resident in HBM",
+           "clips": len(lengths), "frames": frames, "pairs": pairs, "clips_per_forward": a.pack, "evaluator": a.evaluator,
+           "seconds": elapsed, "frames_per_s": frames / elapsed}
+    if ev is not None:
+        out["recall"] = {k: {str(kk): round(float(vv), 4) for kk, vv in v.items()} for k, v in ev.summary().items()}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
