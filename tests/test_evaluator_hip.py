@@ -68,6 +68,18 @@ def test_pack_and_tally_match_host_evaluator(counts):
     _same_results(host.result_dict, mine.result_dict, "predcls")
 
 
+def test_packed_ground_truth_round_trip():
+    pytest.importorskip("torch")
+    from nl_vsgg_amd.lib.evaluation_recall_hip import pack_ground_truth
+    ev = SceneGraphEvaluator(mode="predcls", **KW)
+    gt, _ = _clip(9, [3, 1, 4], jitter=5.0)
+    p1 = pack_ground_truth(gt, ev)
+    p2 = pack_ground_truth(p1.to_annotation(ev), ev)
+    for k in ("box_off", "boxes", "classes", "rel_off"):
+        assert np.array_equal(getattr(p1, k), getattr(p2, k)), k
+    assert sorted(map(tuple, p1.rels.tolist())) == sorted(map(tuple, p2.rels.tolist()))
+
+
 # ---- GPU: the kernel's hit table equals the host evaluator's ---------------------------------------------
 def _device_eval(mode="predcls"):
     from nl_vsgg_amd.lib.evaluation_recall_hip import SceneGraphEvaluator_HIP
