@@ -227,6 +227,23 @@ def main():
                                else "single GPU"},
     }
 
+    # ---- the same clip shape, ONE clip per pass (the reference's own batch size; not `value`) -------------
+    if cps > 1 and world == 1:
+        one = clips[0]
+        for _ in range(3):
+            model(one)
+        torch.cuda.synchronize()
+        n1 = max(2 * args.steps, 20)
+        t0 = time.perf_counter()
+        for _ in range(n1):
+            model(one)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / n1
+        result["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1,
+                                       "note": "same clip shape with clips_per_step = 1 (latency-bound: one clip cannot "
+                                               "fill 256 CUs)"}
+        model(batch)                                    # restore the cached layout of the batch
+
     # ---- PCIe-inclusive rate (never `value`): inputs start in pinned host memory each step ----------
     if args.pcie and world == 1:
         host = {k: v.cpu().pin_memory() for k, v in batch.items() if isinstance(v, torch.Tensor)}
