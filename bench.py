@@ -124,6 +124,9 @@ def main():
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
         dist.init_process_group(backend)
 
+    if args.graph and args.model == "dsgdetr":
+        raise SystemExit("--graph: the DSG-DETR forward reads labels / pair_idx back to build its class sequences "
+                         "(one small D2H + sync per call), so it cannot be captured")
     T, N = (16, 12) if args.workload == "16x12" else (64, 36)
     cps = args.clips_per_step or (16 if args.workload == "16x12" else 1)
     if args.model == "dsgdetr":
