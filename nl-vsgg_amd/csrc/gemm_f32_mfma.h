@@ -49,7 +49,12 @@ struct GemmOperand {
 // when they are loaded); elements are gathered from the channel-last input [pair][7][7][128] on the fly (no
 // im2col buffer).
 // (The 7x7/2 convolution in front of it has its own kernel, kernels_maskconv.hip.)
-enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2 };
+// B_KMAJOR_PAD: K-major rows like B_KMAJOR, with the caller's guarantee that (1) every row of BOTH operands can be read
+// up to the next multiple of 32 columns (finite values) and (2) B is zero there.  Then nothing has to be zeroed while
+// staging: rows past M / N are loaded from a clamped row and never stored by the epilogue, the K tail multiplies
+// whatever A holds by B's zeros.  This removes the select (4 v_cndmask per 16 bytes) from the main loop; it is the
+// product path (weights are stored padded, workspace rows have slack).  B_KMAJOR (with the select) takes any operands.
+enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2, B_KMAJOR_PAD = 3 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
 template <> struct ConvGeo<B_CONV2> {   // Conv2d(128, 256, kernel 3, padding 1) on 7x7 -> 7x7
   static constexpr int KH = 3, S = 1, PAD = 1, HI = 7, HO = 7, CIN = 128, KREAL = 1152;
@@ -197,6 +202,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
   constexpr bool CONV = T::BKIND == B_CONV2;
+  constexpr bool PADDED = T::BKIND == B_KMAJOR_PAD;
   using Geo = ConvGeo<T::BKIND>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -292,12 +298,18 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int ka = 0, kb_src = 0;                        // element offsets of the next load (A side, B side)
     auto set_k = [&](int k0) {
-      // K-major rows: a float4 is all-in or all-out of [k_begin,k_end) because K % 4 == 0.
-      // Union slabs need K % 32 == 0 (checked by the launcher): a K-step is never partial.
-      kok_a = (k0 + kq4) < k_end;
-      kok_b = UNION ? k0 < k_end : kok_a;
-      ka = kok_a ? k0 : 0;
-      kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
+      if constexpr (PADDED) {
+        // whole K-steps are loaded as they are (B is zero past K); only the dummy step after the range is redirected
+        ka = k0 < ks1 * kBK ? k0 : 0;
+        kb_src = ka;
+      } else {
+        // K-major rows: a float4 is all-in or all-out of [k_begin,k_end) because K % 4 == 0.
+        // Union slabs need K % 32 == 0 (checked by the launcher): a K-step is never partial.
+        kok_a = (k0 + kq4) < k_end;
+        kok_b = UNION ? k0 < k_end : kok_a;
+        ka = kok_a ? k0 : 0;
+        kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
+      }
     };
     auto load_piece = [&](int n) {
       if (n < AV) {
@@ -321,8 +333,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     };
     auto store_piece = [&](int n, float* stage) {
       if (n < AV) {
-        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) =
-            (va[n] && kok_a) ? ra[n] : zero4;
+        f32x4* dst = reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4);
+        if constexpr (PADDED) *dst = ra[n];
+        else *dst = (va[n] && kok_a) ? ra[n] : zero4;
       } else {
         const int i = n - AV;
         if constexpr (CONV) {
@@ -330,6 +343,8 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (vb[i] && ((cm[i] >> e) & 1)) ? rb[i][e] : 0.f;
           *reinterpret_cast<f32x4*>(stage + sb[i]) = v;
+        } else if constexpr (PADDED) {
+          *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
         } else if (!UNION || sb[i] >= 0) {
           *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
         }

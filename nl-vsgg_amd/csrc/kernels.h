@@ -15,8 +15,9 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
 size_t gemm_slab_floats_max();   // park space of the stream-K schedule, any tile
 
+// padded: both operands can be read up to ceil32(K) columns per row and B is zero there (gemm_f32_mfma.h, B_KMAJOR_PAD)
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                       const EpiLinear& epi, GemmPlan plan, float* slab);
+                       const EpiLinear& epi, GemmPlan plan, float* slab, int padded);
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab);
 hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, const EpiConvRelBn& epi, int P,

@@ -7,6 +7,7 @@
 
 namespace sttran {
 
+// (the linear GEMMs instantiate GemmTile<...> in gemm_generic)
 using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
@@ -135,25 +136,28 @@ static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, 
 #endif
 }
 
-template <class Epi>
+template <class Epi, int BK>
 static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                                const Epi& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
   switch (plan.tile) {
-    case TILE_256x128: return launch_tile<T256x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_128x128: return launch_tile<T128x128, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_128x64: return launch_tile<T128x64, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    default: return launch_tile<T64x64, Epi>(s, TILE_64x64, A, B, M, N, K, slab, epi);
+    case TILE_256x128: return launch_tile<GemmTile<256, 128, 4, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_128x128: return launch_tile<GemmTile<128, 128, 2, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_128x64: return launch_tile<GemmTile<128, 64, 2, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    default: return launch_tile<GemmTile<64, 64, 2, 2, BK>, Epi>(s, TILE_64x64, A, B, M, N, K, slab, epi);
   }
 }
 
+// padded != 0: the operands meet the B_KMAJOR_PAD contract (gemm_f32_mfma.h); rows must then be 128-byte multiples apart
+// only as far as the caller's ld says -- what matters is that ceil32(K) columns of every row are readable.
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                       const EpiLinear& epi, GemmPlan plan, float* slab) {
-  return gemm_generic<EpiLinear>(s, A, B, M, N, K, epi, plan, slab);
+                       const EpiLinear& epi, GemmPlan plan, float* slab, int padded) {
+  return padded ? gemm_generic<EpiLinear, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab)
+                : gemm_generic<EpiLinear, B_KMAJOR>(s, A, B, M, N, K, epi, plan, slab);
 }
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
-  return gemm_generic<EpiHeads>(s, A, B, M, N, K, epi, plan, slab);
+  return gemm_generic<EpiHeads, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab);     // product only: padded operands
 }
 // union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K
 // over (tile, K-step) like every other GEMM

@@ -19,10 +19,14 @@ using namespace sttran;
 
 namespace {
 
+// columns of a GEMM operand row that must be readable: the next multiple of the K-step (32)
+inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
+
 struct Tensor {
   float* d = nullptr;
   std::vector<int64_t> shape;
   size_t n = 0;
+  int64_t ld = 0;          // != 0: a [rows, cols] GEMM weight stored with this row stride (cols zero-padded to pad32)
   bool required = false, loaded = false;
 };
 
@@ -32,10 +36,13 @@ struct DevBuf {
   hipError_t ensure(size_t need) {
     if (need <= bytes) return hipSuccess;
     if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
-    need = (need + 255) & ~size_t(255);
+    // 256 bytes of slack and zero-initialised: GEMM A operands are read up to pad32(K) columns per row, i.e. up to
+    // 124 bytes past the last row, and what is read there must be finite (it is multiplied by zero-padded weights)
+    need = ((need + 255) & ~size_t(255)) + 256;
     hipError_t e = hipMalloc(&p, need);
-    if (e == hipSuccess) bytes = need;
-    return e;
+    if (e != hipSuccess) return e;
+    bytes = need;
+    return hipMemset(p, 0, need);
   }
   void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -104,24 +111,26 @@ int fail(SttranHandle* h, int code, const std::string& msg) {
       return fail(h, STTRAN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
   } while (0)
 
-void add(SttranHandle* h, const std::string& k, std::vector<int64_t> shape, bool required) {
+void add(SttranHandle* h, const std::string& k, std::vector<int64_t> shape, bool required, bool gemm_weight = false) {
   Tensor t;
   t.shape = std::move(shape);
   t.n = 1;
   for (int64_t d : t.shape) t.n *= (size_t)d;
   t.required = required;
+  if (gemm_weight) t.ld = pad32(t.shape.back());
   h->w[k] = t;
 }
 
-void add_linear(SttranHandle* h, const std::string& p, int64_t out, int64_t in, bool req) {
-  add(h, p + ".weight", {out, in}, req);
+// gemm = the weight is the B operand of run_linear: stored with zero-padded rows (B_KMAJOR_PAD contract)
+void add_linear(SttranHandle* h, const std::string& p, int64_t out, int64_t in, bool req, bool gemm = true) {
+  add(h, p + ".weight", {out, in}, req, gemm);
   add(h, p + ".bias", {out}, req);
 }
 void add_bn(SttranHandle* h, const std::string& p, int64_t n, bool req) {
   for (const char* s : {".weight", ".bias", ".running_mean", ".running_var"}) add(h, p + s, {n}, req);
 }
 void add_mha(SttranHandle* h, const std::string& p, int64_t d) {
-  add(h, p + ".in_proj_weight", {3 * d, d}, true);
+  add(h, p + ".in_proj_weight", {3 * d, d}, true, true);
   add(h, p + ".in_proj_bias", {3 * d}, true);
   add_linear(h, p + ".out_proj", d, d, true);
 }
@@ -133,7 +142,7 @@ void declare_weights(SttranHandle* h) {
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   add(h, "object_classifier.obj_embed.weight", {NC - 1, 200}, oc);
   add_bn(h, "object_classifier.pos_embed.0", 4, oc);
-  add_linear(h, "object_classifier.pos_embed.1", 128, 4, oc);
+  add_linear(h, "object_classifier.pos_embed.1", 128, 4, oc, false);            // read by objcls_prep_kernel, dense
   add_linear(h, "object_classifier.decoder_lin.0", 1024, FD + 200 + 128, oc);
   add_bn(h, "object_classifier.decoder_lin.1", 1024, oc);
   add_linear(h, "object_classifier.decoder_lin.3", NC, 1024, oc);
@@ -179,9 +188,9 @@ void declare_weights(SttranHandle* h) {
     add(h, p + ".norm3.weight", {D}, true); add(h, p + ".norm3.bias", {D}, true);
   }
   if (c.model != STTRAN_MODEL_DSG_DETR) add(h, "glocal_transformer.position_embedding.weight", {2, D}, true);
-  add_linear(h, "a_rel_compress", c.attention_classes, D, true);
-  add_linear(h, "s_rel_compress", c.spatial_classes, D, true);
-  add_linear(h, "c_rel_compress", c.contact_classes, D, true);
+  add_linear(h, "a_rel_compress", c.attention_classes, D, true, false);         // packed (and padded) into heads_w
+  add_linear(h, "s_rel_compress", c.spatial_classes, D, true, false);
+  add_linear(h, "c_rel_compress", c.contact_classes, D, true, false);
 }
 
 const float* W(SttranHandle* h, const std::string& k) { return h->w[k].d; }
@@ -218,9 +227,9 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     HIPCK(hipStreamSynchronize(s));
     HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
   }
-  GemmOperand B{Wt, (int64_t)K, nullptr, 0};
+  GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
-  HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>()));
+  HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>(), 1));
   return STTRAN_OK;
 }
 
@@ -476,8 +485,23 @@ int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const
   for (int i = 0; same && i < ndim; ++i) same = shape[i] == t.shape[i];
   if (!same || n != t.n) return fail(h, STTRAN_ERR_INVALID, std::string(key) + ": shape mismatch");
   HIPCK(hipSetDevice(h->cfg.device));
-  if (!t.d) HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), std::max<size_t>(t.n * 4, 16)));
-  HIPCK(hipMemcpy(t.d, data, t.n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (t.ld) {
+    // GEMM weight: rows zero-padded to pad32(cols) (B_KMAJOR_PAD contract, csrc/gemm_f32_mfma.h)
+    const size_t rows = (size_t)t.shape[0], cols = (size_t)t.shape[1], bytes = rows * (size_t)t.ld * 4 + 256;
+    if (!t.d) {
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), bytes));
+      HIPCK(hipMemset(t.d, 0, bytes));
+    }
+    HIPCK(hipMemcpy2D(t.d, (size_t)t.ld * 4, data, cols * 4, cols * 4, rows, kind));
+  } else {
+    // 256 zeroed bytes of slack: position_embedding.weight is a GEMM A operand (read up to pad32(K) per row)
+    if (!t.d) {
+      HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), t.n * 4 + 256));
+      HIPCK(hipMemset(t.d, 0, t.n * 4 + 256));
+    }
+    HIPCK(hipMemcpy(t.d, data, t.n * 4, kind));
+  }
   t.loaded = true;
   h->finalized = false;
   return STTRAN_OK;
@@ -507,13 +531,13 @@ int sttran_finalize_weights(SttranHandle* h) {
   const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   // arena layout (floats)
-  size_t total = 2 * 128 + 2 * 256 + 128 * 104 + 256 * 1152 + (size_t)nh * D + 64 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  size_t total = 2 * 128 + 2 * 256 + 128 * 104 + 256 * 1152 + (size_t)nh * pad32(D) + 128 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
   HIPCK(h->derived.ensure(total * 4));
   float* p = h->derived.as<float>();
   auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
   h->bn1_scale = take(128); h->bn1_shift = take(128);
   h->bn2_scale = take(256); h->bn2_shift = take(256);
-  h->heads_w = take((size_t)nh * D); h->heads_b = take(64);
+  h->heads_w = take((size_t)nh * pad32(D) + 64); h->heads_b = take(64);
   h->w0_perm = take(128 * 104);
   h->w4_perm = take(256 * 1152);
   h->dec.resize(c.dec_layers);
@@ -570,8 +594,8 @@ int sttran_finalize_weights(SttranHandle* h) {
                                                {"s_rel_compress", c.spatial_classes},
                                                {"c_rel_compress", c.contact_classes}};
     for (auto& kv : hs) {
-      HIPCK(hipMemcpy(h->heads_w + ro * D, W(h, std::string(kv.first) + ".weight"), (size_t)kv.second * D * 4,
-                      hipMemcpyDeviceToDevice));
+      HIPCK(hipMemcpy2D(h->heads_w + ro * pad32(D), (size_t)pad32(D) * 4, W(h, std::string(kv.first) + ".weight"),
+                        (size_t)D * 4, (size_t)D * 4, (size_t)kv.second, hipMemcpyDeviceToDevice));
       HIPCK(hipMemcpy(h->heads_b + ro, W(h, std::string(kv.first) + ".bias"), (size_t)kv.second * 4,
                       hipMemcpyDeviceToDevice));
       ro += kv.second;
@@ -855,7 +879,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       } else {
         EpiLinear ekv = epi_plain(QKV + D, 3 * D, bin + D);                 // k | v columns, all tokens
         ekv.rowbias = h->dec[i].posbias + D; ekv.rowslot = slot; ekv.rb_cols = D; ekv.rb_ld = 2 * D;
-        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win + (size_t)D * D, NT, 2 * D, D, ekv))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win + (size_t)D * pad32(D), NT, 2 * D, D, ekv))) return rc;
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);                          // q columns, needed rows only
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = D; eq.rb_ld = 2 * D;
         eq.out_rowidx = need;
@@ -893,7 +917,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                 c.attention_classes, c.spatial_classes, c.contact_classes};
     GemmPlan plan = plan_gemm(P, nh, D, TILE_64x64, 1);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D));
-    HIPCK(gemm_heads(s, GemmOperand{UNI, D, out_src}, GemmOperand{h->heads_w, D, nullptr}, (int)P, nh, D, eh, plan,
+    HIPCK(gemm_heads(s, GemmOperand{UNI, D, out_src}, GemmOperand{h->heads_w, pad32(D), nullptr}, (int)P, nh, D, eh, plan,
                      h->slab.as<float>()));
   }
   if (h->prof_on) h->prof.forwards += 1;
@@ -957,8 +981,10 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, 
     return STTRAN_ERR_HIP;
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
+  // arbitrary caller tensors: the select path (B_KMAJOR); with K % 32 == 0 there is no K tail, so the select-free
+  // product path (B_KMAJOR_PAD) is equally valid and is what gets measured
   hipError_t err = gemm_linear(s, GemmOperand{A, K, a_rowidx}, GemmOperand{Wt, K, nullptr}, (int)M, (int)N, (int)K,
-                               e, plan, slab);
+                               e, plan, slab, K % 32 == 0 ? 1 : 0);
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
