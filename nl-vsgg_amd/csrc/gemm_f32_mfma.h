@@ -477,6 +477,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         __builtin_amdgcn_sched_barrier(0);
         if (PIPE != 3 && PIPE != 5) __syncthreads();     // PIPE 3/4/5: timing-only ablations (wrong results)
         read_frags(nxt, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);      // issue these reads BEFORE the held-over MFMA group, which then hides them
         mma(fa1, fb1);
       }
     }
