@@ -334,7 +334,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     auto store_piece = [&](int n, float* stage) {
       if (n < AV) {
         f32x4* dst = reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4);
-        if constexpr (PADDED) *dst = ra[n];
+        // the union conv and the 3x3 conv have M = 256 output channels (a whole number of tiles) and K % 32 == 0
+        // (their launchers check both): every A piece is valid, like on the padded path
+        if constexpr (PADDED || UNION || CONV) *dst = ra[n];
         else *dst = (va[n] && kok_a) ? ra[n] : zero4;
       } else {
         const int i = n - AV;
@@ -345,7 +347,10 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
           *reinterpret_cast<f32x4*>(stage + sb[i]) = v;
         } else if constexpr (PADDED) {
           *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
-        } else if (!UNION || sb[i] >= 0) {
+        } else if constexpr (UNION) {
+          // pairs past P were loaded from pair 0 (clamped): their columns are dropped by EpiUnion, nothing to zero
+          if (sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
+        } else {
           *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
         }
       }

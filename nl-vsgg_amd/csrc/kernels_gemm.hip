@@ -163,7 +163,7 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
 // over (tile, K-step) like every other GEMM
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V, int P,
                              int K, float* slab) {
-  if (K % kBK != 0 || P <= 0) return hipErrorInvalidValue;
+  if (K % kBK != 0 || P <= 0) return hipErrorInvalidValue;      // (M = 256 = 2 x BM: no A piece is ever invalid)
   const int groups = (P + kUPairs - 1) / kUPairs;
   GemmOperand A{W, (int64_t)K, nullptr, 0};
   GemmOperand B{U, (int64_t)K * kUHW, nullptr, P};
