@@ -388,11 +388,42 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
-    set_k(k_begin);
+    // Operand kinds without per-step validity state (padded K-major rows, union slabs) prefetch TWO K-steps
+    // ahead: the global loads of step t+2 are issued during step t into one of two register sets and written to
+    // LDS during step t+1, so a load has a K-step and a half (~5 us) to arrive instead of half a K-step -- what
+    // the operands need when they come from HBM rather than from a warm cache (tools/gemm_bench.py --cold).
+    constexpr bool DEEP = (PADDED || UNION) && PIPE == 1;
+    f32x4 ra2[DEEP ? AV : 1], rb2[DEEP ? BV : 1];       // second register set
+    // element offsets of K-step u of this range (the steps past its end read step 0 again, into an idle buffer)
+    auto koff_a = [&](int u) { const int k0 = k_begin + u * kBK; return k0 < ks1 * kBK ? k0 : 0; };
+    auto koff_b = [&](int u) { return UNION ? koff_a(u) * kUHW : koff_a(u); };
+    auto load_to = [&](int n, auto& RA, auto& RB, int ka_, int kb_) {
+      if (n < AV) RA[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka_);
+      else RB[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_);
+    };
+    auto store_from = [&](int n, float* stage, const auto& RA, const auto& RB) {
+      if (n < AV) {
+        *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) = RA[n];
+      } else {
+        const int i = n - AV;
+        if constexpr (UNION) { if (sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i]; }
+        else *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i];
+      }
+    };
+    if constexpr (DEEP) {
 #pragma unroll
-    for (int n = 0; n < AV + BV; ++n) load_piece(n);
+      for (int n = 0; n < AV + BV; ++n) load_to(n, ra, rb, koff_a(0), koff_b(0));
 #pragma unroll
-    for (int n = 0; n < AV + BV; ++n) store_piece(n, smem);
+      for (int n = 0; n < AV + BV; ++n) load_to(n, ra2, rb2, koff_a(1), koff_b(1));
+#pragma unroll
+      for (int n = 0; n < AV + BV; ++n) store_from(n, smem, ra, rb);
+    } else {
+      set_k(k_begin);
+#pragma unroll
+      for (int n = 0; n < AV + BV; ++n) load_piece(n);
+#pragma unroll
+      for (int n = 0; n < AV + BV; ++n) store_piece(n, smem);
+    }
     __syncthreads();
     if constexpr (PIPE == 0) {
       // plain loop (kept for A/B runs of tools/gemm_bench.py): fragments of group kb are read right
@@ -425,6 +456,73 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       constexpr int NP = AV + BV, NM = 4 * TM * TN;
       f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
       read_frags(smem, 0, fa0, fb0);
+      // one K-step of the two-deep variant: `RAL/RBL` receive the loads of step t+2, `RAS/RBS` (loaded one step
+      // earlier) are written to the other LDS stage
+      auto deep_step = [&](int t, auto& RAL, auto& RBL, const auto& RAS, const auto& RBS) {
+        const float* cur = smem + (t & 1) * T::STAGE;
+        float* nxt = smem + ((t + 1) & 1) * T::STAGE;
+        const int ka_ = koff_a(t + 2), kb_ = koff_b(t + 2);
+        read_frags(cur, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          int n = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                if (n < NP) load_to(n, RAL, RBL, ka_, kb_);
+                ++n;
+              }
+#pragma unroll
+          for (; n < NP; ++n) load_to(n, RAL, RBL, ka_, kb_);
+#pragma unroll
+          for (int q = 0; q < NP && q < NM; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 2, fa0, fb0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(cur, 3, fa1, fb1);
+        {
+          int n = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                if (n < NP) store_from(n, nxt, RAS, RBS);
+                ++n;
+              }
+#pragma unroll
+          for (; n < NP; ++n) store_from(n, nxt, RAS, RBS);
+#pragma unroll
+          for (int q = 0; q < NP && q < NM; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(nxt, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+      };
+      if constexpr (DEEP) {
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {
+          deep_step(t, ra, rb, ra2, rb2);          // even step: set 0 is free (stored), set 1 holds step t+1
+          deep_step(t + 1, ra2, rb2, ra, rb);
+        }
+        if (t < nsteps) deep_step(t, ra, rb, ra2, rb2);
+      } else
       for (int t = 0; t < nsteps; ++t) {
         const float* cur = smem + (t & 1) * T::STAGE;
         float* nxt = smem + ((t + 1) & 1) * T::STAGE;
