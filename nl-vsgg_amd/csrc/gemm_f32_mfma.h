@@ -392,31 +392,47 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     // ahead: the global loads of step t+2 are issued during step t into one of two register sets and written to
     // LDS during step t+1, so a load has a K-step and a half (~5 us) to arrive instead of half a K-step -- what
     // the operands need when they come from HBM rather than from a warm cache (tools/gemm_bench.py --cold).
-    constexpr bool DEEP = (PADDED || UNION) && PIPE == 1;
+    constexpr bool DEEP = (PADDED || UNION || CONV) && PIPE == 1;
     f32x4 ra2[DEEP ? AV : 1], rb2[DEEP ? BV : 1];       // second register set
+    int cm2[BV];                                         // ... and its conv tap masks
+    (void)cm2;
     // element offsets of K-step u of this range (the steps past its end read step 0 again, into an idle buffer)
     auto koff_a = [&](int u) { const int k0 = k_begin + u * kBK; return k0 < ks1 * kBK ? k0 : 0; };
     auto koff_b = [&](int u) { return UNION ? koff_a(u) * kUHW : koff_a(u); };
-    auto load_to = [&](int n, auto& RA, auto& RB, int ka_, int kb_) {
-      if (n < AV) RA[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka_);
-      else RB[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_);
+    auto load_to = [&](int n, auto& RA, auto& RB, auto& CM, int ka_, int kb_) {
+      if (n < AV) {
+        RA[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka_);
+      } else if constexpr (CONV) {
+        // (ky, kx, ci) K order over a channel-last input: one tap per K-step, 4 channels = one 16-byte load; a tap
+        // outside the image is a zero piece (CM), loaded from a clamped address
+        const int i = n - AV;
+        const int tap = ka_ / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH;
+        const int ci = ka_ - tap * Geo::CIN + kq4;
+        const int iy = cy[i] + ky, ix = cx[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
+        RB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci : 0));
+        CM[i] = ok;
+      } else {
+        RB[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_);
+      }
     };
-    auto store_from = [&](int n, float* stage, const auto& RA, const auto& RB) {
+    auto store_from = [&](int n, float* stage, const auto& RA, const auto& RB, const auto& CM) {
       if (n < AV) {
         *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) = RA[n];
       } else {
         const int i = n - AV;
         if constexpr (UNION) { if (sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i]; }
+        else if constexpr (CONV) *reinterpret_cast<f32x4*>(stage + sb[i]) = CM[i] ? RB[i] : zero4;
         else *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i];
       }
     };
     if constexpr (DEEP) {
 #pragma unroll
-      for (int n = 0; n < AV + BV; ++n) load_to(n, ra, rb, koff_a(0), koff_b(0));
+      for (int n = 0; n < AV + BV; ++n) load_to(n, ra, rb, cm, koff_a(0), koff_b(0));
 #pragma unroll
-      for (int n = 0; n < AV + BV; ++n) load_to(n, ra2, rb2, koff_a(1), koff_b(1));
+      for (int n = 0; n < AV + BV; ++n) load_to(n, ra2, rb2, cm2, koff_a(1), koff_b(1));
 #pragma unroll
-      for (int n = 0; n < AV + BV; ++n) store_from(n, smem, ra, rb);
+      for (int n = 0; n < AV + BV; ++n) store_from(n, smem, ra, rb, cm);
     } else {
       set_k(k_begin);
 #pragma unroll
@@ -458,7 +474,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       read_frags(smem, 0, fa0, fb0);
       // one K-step of the two-deep variant: `RAL/RBL` receive the loads of step t+2, `RAS/RBS` (loaded one step
       // earlier) are written to the other LDS stage
-      auto deep_step = [&](int t, auto& RAL, auto& RBL, const auto& RAS, const auto& RBS) {
+      auto deep_step = [&](int t, auto& RAL, auto& RBL, auto& CML, const auto& RAS, const auto& RBS, const auto& CMS) {
         const float* cur = smem + (t & 1) * T::STAGE;
         float* nxt = smem + ((t + 1) & 1) * T::STAGE;
         const int ka_ = koff_a(t + 2), kb_ = koff_b(t + 2);
@@ -473,11 +489,11 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < NP) load_to(n, RAL, RBL, ka_, kb_);
+                if (n < NP) load_to(n, RAL, RBL, CML, ka_, kb_);
                 ++n;
               }
 #pragma unroll
-          for (; n < NP; ++n) load_to(n, RAL, RBL, ka_, kb_);
+          for (; n < NP; ++n) load_to(n, RAL, RBL, CML, ka_, kb_);
 #pragma unroll
           for (int q = 0; q < NP && q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -498,14 +514,15 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
-                if (n < NP) store_from(n, nxt, RAS, RBS);
+                if (n < NP) store_from(n, nxt, RAS, RBS, CMS);
                 ++n;
               }
 #pragma unroll
-          for (; n < NP; ++n) store_from(n, nxt, RAS, RBS);
+          for (; n < NP; ++n) store_from(n, nxt, RAS, RBS, CMS);
 #pragma unroll
           for (int q = 0; q < NP && q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+            if constexpr (CONV) __builtin_amdgcn_sched_group_barrier(0x2, 4, 1);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);
           }
         }
@@ -518,10 +535,10 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       if constexpr (DEEP) {
         int t = 0;
         for (; t + 1 < nsteps; t += 2) {
-          deep_step(t, ra, rb, ra2, rb2);          // even step: set 0 is free (stored), set 1 holds step t+1
-          deep_step(t + 1, ra2, rb2, ra, rb);
+          deep_step(t, ra, rb, cm, ra2, rb2, cm2);          // even step: set 0 is free (stored), set 1 holds step t+1
+          deep_step(t + 1, ra2, rb2, cm2, ra, rb, cm);
         }
-        if (t < nsteps) deep_step(t, ra, rb, ra2, rb2);
+        if (t < nsteps) deep_step(t, ra, rb, cm, ra2, rb2, cm2);
       } else
       for (int t = 0; t < nsteps; ++t) {
         const float* cur = smem + (t & 1) * T::STAGE;
