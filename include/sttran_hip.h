@@ -206,6 +206,12 @@ int sttran_profile_read(SttranHandle* h, SttranProfile* out); /* synchronises th
 int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* W, const float* bias,
                       const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                       int32_t relu, int32_t tile_cfg, int32_t split_k, void* stream);
+/* The product's GEMM path (select-free, two-deep prefetch): A rows `lda` and W rows `ldw` floats apart, both readable
+ * (finite) up to the next multiple of 32 columns past K, and W zero there -- how the library stores every nn.Linear
+ * weight and lays out its workspace (csrc/gemm_f32_mfma.h, B_KMAJOR_PAD). */
+int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
+                             const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                             int32_t relu, int32_t tile_cfg, void* stream);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
 int sttran_debug_mfma_peak(int32_t iters, double* tflops);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */

@@ -20,7 +20,7 @@ struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
 // (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 128, 0.85f, 1}, {128, 128, 0.83f, 2}, {64, 64, 0.74f, 4}, {128, 64, 0.77f, 2},
+    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
     {128, 256, 0.80f, 1}};   // last: TILE_UNION (never chosen by plan_gemm)
 
 static int num_cus() {

@@ -988,6 +988,23 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, 
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+                             const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                             int32_t relu, int32_t tile_cfg, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < pad32(K) || ldw < pad32(K) || (lda & 3) || (ldw & 3))
+    return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmPlan plan = plan_gemm(M, N, K, tile_cfg, 0);
+  static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
+  if (!slab && hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_floats_max() * 4) != hipSuccess)
+    return STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  hipError_t err = gemm_linear(s, GemmOperand{A, lda, a_rowidx}, GemmOperand{Wt, ldw, nullptr}, (int)M, (int)N, (int)K,
+                               e, plan, slab, 1);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
 int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
   if (iters <= 0 || !tflops) return STTRAN_ERR_INVALID;
   float* out = nullptr;

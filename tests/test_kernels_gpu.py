@@ -62,6 +62,29 @@ def test_gemm_tiles(lib, M, N, K, tile):
     assert (out.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
 
 
+@pytest.mark.parametrize("M,N,K", [(2, 3872, 1936), (33, 70, 100), (330, 5808, 1936), (257, 129, 36), (300, 26, 1936),
+                                   (2816, 1936, 1936), (64, 64, 32), (5280, 1936, 2048), (200, 1024, 2376)])
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_gemm_padded_path(lib, M, N, K, tile):
+    """the product path: rows padded to a multiple of 32 columns, W zero there, A holding arbitrary finite values there
+    (they must not reach the result), no zero-select in the kernel, loads two K-steps ahead"""
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 5 * K + tile)
+    Kp = (K + 31) // 32 * 32
+    A = torch.randn(M + 1, Kp, device="cuda", generator=g) * 3          # pad columns: garbage; +1 row of slack
+    W = torch.zeros(N, Kp, device="cuda")
+    W[:, :K] = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    rc = lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(W), Kp, _p(b), _p(res), _p(Cc), M, N, K, 1, tile, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = _ref(A[:M, :K], W[:, :K], b, res, relu=1)
+    tol = 1e-5 * (K ** 0.5) * 12 + 1e-5
+    assert torch.isfinite(Cc).all()
+    assert (Cc.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
+
+
 @pytest.mark.parametrize("split", [2, 4, 8])
 def test_gemm_split_k(lib, split):
     g = torch.Generator(device="cuda").manual_seed(split)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the fp32 MFMA GEMM (sttran_debug_gemm) per (shape, tile, split-K).
+"""Micro-benchmark of the fp32 MFMA GEMM (sttran_debug_gemm_padded: the product's operand layout) per (shape, tile).
 Used to tune the tile planner (csrc/kernels_gemm.hip); run on the GPU box:
     python tools/gemm_bench.py [--shapes big|path64|path16|path16x8] [--tiles 1,2,3,4,5]"""
 import argparse
@@ -52,8 +52,10 @@ def main():
     print(f"device fp32-MFMA rate (register-only loop): {pk.value:.1f} TFLOP/s (spec peak 157.3)")
     flush = torch.zeros(192 * 1024 * 1024, device="cuda") if a.cold else None
     for name, M, N, K in SHAPES[a.shapes]:
-        A = torch.randn(M, K, device="cuda")
-        W = torch.randn(N, K, device="cuda")
+        Kp = (K + 31) // 32 * 32                     # the product's layout: rows padded to 32 columns, W zero there
+        A = torch.randn(M + 1, Kp, device="cuda")
+        W = torch.zeros(N, Kp, device="cuda")
+        W[:, :K] = torch.randn(N, K, device="cuda")
         if a.zeros:
             A.zero_(); W.zero_()
         b = torch.randn(N, device="cuda")
@@ -64,7 +66,7 @@ def main():
             for split in ([0] if tile == 0 else [int(s) for s in a.pipes.split(",")]):
                 os.environ["STTRAN_GEMM_PIPE"] = str(split)     # only read by EXPERIMENT builds
                 for _ in range(2):
-                    lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                    lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 if a.cold:
@@ -72,14 +74,14 @@ def main():
                     for _ in range(a.iters):
                         flush.add_(1.0)
                         e0.record()
-                        lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
                         e1.record()
                         torch.cuda.synchronize()
                         us += e0.elapsed_time(e1) * 1e3 / a.iters
                 else:
                     e0.record()
                     for _ in range(a.iters):
-                        lib.sttran_debug_gemm(p(A), None, p(W), p(b), None, p(Cc), M, N, K, 0, tile, split, None)
+                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
                     e1.record()
                     torch.cuda.synchronize()
                     us = e0.elapsed_time(e1) * 1e3 / a.iters
