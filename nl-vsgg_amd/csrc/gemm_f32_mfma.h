@@ -53,7 +53,9 @@ struct GemmOperand {
 // up to the next multiple of 32 columns (finite values) and (2) B is zero there.  Then nothing has to be zeroed while
 // staging: rows past M / N are loaded from a clamped row and never stored by the epilogue, the K tail multiplies
 // whatever A holds by B's zeros.  This removes the select (4 v_cndmask per 16 bytes) from the main loop; it is the
-// product path (weights are stored padded, workspace rows have slack).  B_KMAJOR (with the select) takes any operands.
+// product path: weights are stored with zero-padded rows, and every activation buffer has a row stride of ceil32(K)
+// floats whose pad columns are zeroed once and never written (sttran_api.hip::ensure_workspace), so the K tail is
+// 0 x 0 whatever earlier calls left in the workspace.  B_KMAJOR (with the select) takes any operands.
 enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2, B_KMAJOR_PAD = 3 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
 template <> struct ConvGeo<B_CONV2> {   // Conv2d(128, 256, kernel 3, padding 1) on 7x7 -> 7x7

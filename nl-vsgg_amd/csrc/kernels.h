@@ -7,6 +7,29 @@
 
 namespace sttran {
 
+// ---- per-device launch state -----------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a DEVICE, and sttran_create() accepts
+// any ordinal: every launcher keeps its "attribute already raised to N bytes" mark and the planner its CU count
+// per device ordinal (relaxed atomics: two threads racing on the same device set the same value twice).
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+struct DeviceMarks {
+  int v[kMaxDevices] = {};
+  // raise `fn`'s dynamic-LDS limit on the current device to `bytes` unless a previous call already did
+  hipError_t raise_lds(const void* fn, int bytes) {
+    const int d = current_device();
+    if (__atomic_load_n(&v[d], __ATOMIC_RELAXED) >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_store_n(&v[d], bytes, __ATOMIC_RELAXED);
+    return e;
+  }
+};
+int num_cus();   // compute units of the current device (cached per ordinal)
+
 // ---- GEMM ------------------------------------------------------------------------------
 enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_UNION = 5,
        TILE_COUNT = 6 };
@@ -56,23 +79,25 @@ hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int
                                     int P, int pool, float* union_boxes, float* masks);
 
 // ---- transformer pieces ----------------------------------------------------------------------
-hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
-                            int64_t rows, int dim);
+// x rows ldx floats apart, y rows ldy floats apart (the workspace keeps [*, 1936] activations at a row stride of 1952)
+hipError_t launch_layernorm(hipStream_t s, const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                            int64_t ldy, int64_t rows, int dim);
 // q_begin (optional, per sequence): compute only query rows [q_begin, len)
+// qkv rows are 3*dim floats apart, out rows ldo floats apart
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
-                            const int* q_begin, int num_seq, int max_len, float* out, int dim, int nhead);
+                            const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead);
 constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel accepts
-hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
-                              int dim);
+hipError_t launch_gather_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, float* dst, int64_t ldd,
+                              int64_t rows, int dim);
 
-hipError_t launch_gather_add_rows(hipStream_t s, const float* src, const int* idx, const float* table,
-                                  const int* tidx, float* dst, int64_t rows, int dim);
+hipError_t launch_gather_add_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, const float* table,
+                                  int64_t ldt, const int* tidx, float* dst, int64_t ldd, int64_t rows, int dim);
 
 // ---- ObjectClassifier sgdet+wks (lib/sttran.py:173-184) ---------------------------------------
 // z[b] = [features[b] | distribution[b] @ E0 | ReLU(Linear(BN(center_size(box))))]   -> [B, 2376]
 hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,
                               const float* E0, const float* pos_scale, const float* pos_shift,
-                              const float* pos_w, const float* pos_b, float* z, int B, int feat_dim,
+                              const float* pos_w, const float* pos_b, float* z, int64_t ldz, int B, int feat_dim,
                               int ncls, int emb_dim);
 
 }  // namespace sttran

@@ -42,7 +42,7 @@ __device__ __forceinline__ void stage_head_rows(float* dst, const float* __restr
 
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
-                 float* __restrict__ out, int dim, int hd, float scale, int skp) {
+                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
   const int L = seq_len[s];
@@ -123,15 +123,15 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
       }
     }
   }
-  float* op = out + (int64_t)(base + q0) * dim + h * hd;
+  float* op = out + (int64_t)(base + q0) * ldo + h * hd;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int q = (e & 3) + 8 * (e >> 2) + 4 * fh;
     if (q0 + q < L) {
       const float ri = rinv[q];
       const int c0 = d0 + fr, c1 = d0 + 32 + fr;
-      if (c0 < hd) op[(int64_t)q * dim + c0] = o0[e] * ri;
-      if (c1 < hd) op[(int64_t)q * dim + c1] = o1[e] * ri;
+      if (c0 < hd) op[(int64_t)q * ldo + c0] = o0[e] * ri;
+      if (c1 < hd) op[(int64_t)q * ldo + c1] = o1[e] * ri;
     }
   }
 }
@@ -190,7 +190,7 @@ template <int CHUNK, int VW, int MAXROWS, int MINWG>
 __global__ void __launch_bounds__(256, MINWG)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
                        const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
-                       int dim, int hd, float scale, int l16max) {
+                       int64_t ldo, int dim, int hd, float scale, int l16max) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kMaxQ = MAXROWS / 16;                   // query (and key) tiles of 16 rows
   constexpr int TPW = (kMaxQ * kMaxQ + 3) / 4;          // score tiles per wave
@@ -329,7 +329,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
       }
     }
   }
-  float* op = out + (int64_t)(base + qb) * dim + h * hd;
+  float* op = out + (int64_t)(base + qb) * ldo + h * hd;
 #pragma unroll
   for (int qi = 0; qi < kMaxQ; ++qi) {
     if (qi < nq) {
@@ -339,7 +339,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int q = qi * 16 + 4 * g + e;
-          if (q < Lq && d < hd) op[(int64_t)q * dim + d] = o[qi][dt][e];
+          if (q < Lq && d < hd) op[(int64_t)q * ldo + d] = o[qi][dt][e];
         }
       }
     }
@@ -347,7 +347,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
 }
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
-                            const int* q_begin, int num_seq, int max_len, float* out, int dim, int nhead) {
+                            const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || max_len <= 0) return hipSuccess;
   const int hd = dim / nhead;
   if (hd > kHdPad - 2 || (hd & 1) || max_len > kAttnMaxKeys) return hipErrorInvalidValue;
@@ -358,31 +358,23 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
     const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
     const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
-    static int attr_max[2] = {0, 0};
+    static DeviceMarks marks[2];
     auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    if (lds > attr_max[small]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-      attr_max[small] = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, dim, hd,
-                       scale, l16);
+    hipError_t e = marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, ldo, dim,
+                       hd, scale, l16);
     return hipGetLastError();
   }
   // the long-sequence kernel computes every query row: q_begin is an optimisation hint only (rows before
   // it are never read by the caller), so it is simply not used here
   const int skp = (max_len + 31) / 32 * 32;
   const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
-  static int attr_max_long = 0;
-  if (lds > attr_max_long) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_max_long = lds;
-  }
+  static DeviceMarks marks_long;
+  hipError_t e = marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
+  if (e != hipSuccess) return e;
   dim3 grid((max_len + 31) / 32, nhead, num_seq);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, dim, hd, scale, skp);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp);
   return hipGetLastError();
 }
 
@@ -393,13 +385,13 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
 constexpr int kLnMaxV = 16;   // float4 per lane -> dim <= 4096
 
 __global__ void __launch_bounds__(256)
-layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                 float* __restrict__ y, int64_t rows, int dim) {
+layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, float* __restrict__ y, int64_t ldy, int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int n4 = dim >> 2;
-  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * dim);
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
   f32x4 v[kLnMaxV];
   float s = 0.f;
 #pragma unroll
@@ -423,7 +415,7 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = 1.0f / sqrtf(q / (float)dim + 1e-5f);
-  f32x4* yr = reinterpret_cast<f32x4*>(y + row * dim);
+  f32x4* yr = reinterpret_cast<f32x4*>(y + row * ldy);
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
   const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
 #pragma unroll
@@ -439,53 +431,55 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, c
   }
 }
 
-hipError_t launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, float* y,
-                            int64_t rows, int dim) {
+hipError_t launch_layernorm(hipStream_t s, const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                            int64_t ldy, int64_t rows, int dim) {
   if (rows <= 0) return hipSuccess;
-  if ((dim & 3) || dim > kLnMaxV * 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, y,
+  if ((dim & 3) || dim > kLnMaxV * 256 || (ldx & 3) || (ldy & 3) || ldx < dim || ldy < dim) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy,
                      rows, dim);
   return hipGetLastError();
 }
 
 // dst[r, :] = src[idx[r], :]   (window build lib/transformer.py:153, 'latter' scatter :181-185)
 __global__ void __launch_bounds__(256)
-gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
-                   int64_t rows, int n4) {
+gather_rows_kernel(const float* __restrict__ src, int64_t lds4, const int* __restrict__ idx, float* __restrict__ dst,
+                   int64_t ldd4, int64_t rows, int n4) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
-  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * n4;
-  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * n4;
+  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * lds4;
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * ldd4;
   for (int j = threadIdx.x; j < n4; j += 256) d[j] = s[j];
 }
 
-hipError_t launch_gather_rows(hipStream_t s, const float* src, const int* idx, float* dst, int64_t rows,
-                              int dim) {
+hipError_t launch_gather_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, float* dst, int64_t ldd,
+                              int64_t rows, int dim) {
   if (rows <= 0) return hipSuccess;
-  if (dim & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, idx, dst, rows, dim >> 2);
+  if ((dim & 3) || (lds & 3) || (ldd & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, lds >> 2, idx, dst, ldd >> 2, rows,
+                     dim >> 2);
   return hipGetLastError();
 }
 
 // dst[r, :] = src[idx[r], :] + table[tidx[r], :]   (DSG-DETR: sequence gather + sinusoidal PE,
 // lib/dsg_detr.py:42-46,556-559)
 __global__ void __launch_bounds__(256)
-gather_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ table,
-                       const int* __restrict__ tidx, float* __restrict__ dst, int64_t rows, int n4) {
+gather_add_rows_kernel(const float* __restrict__ src, int64_t lds4, const int* __restrict__ idx,
+                       const float* __restrict__ table, int64_t ldt4, const int* __restrict__ tidx,
+                       float* __restrict__ dst, int64_t ldd4, int64_t rows, int n4) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
-  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * n4;
-  const f32x4* t = reinterpret_cast<const f32x4*>(table) + (int64_t)tidx[row] * n4;
-  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * n4;
+  const f32x4* s = reinterpret_cast<const f32x4*>(src) + (int64_t)idx[row] * lds4;
+  const f32x4* t = reinterpret_cast<const f32x4*>(table) + (int64_t)tidx[row] * ldt4;
+  f32x4* d = reinterpret_cast<f32x4*>(dst) + row * ldd4;
   for (int j = threadIdx.x; j < n4; j += 256) d[j] = s[j] + t[j];
 }
 
-hipError_t launch_gather_add_rows(hipStream_t s, const float* src, const int* idx, const float* table,
-                                  const int* tidx, float* dst, int64_t rows, int dim) {
+hipError_t launch_gather_add_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, const float* table,
+                                  int64_t ldt, const int* tidx, float* dst, int64_t ldd, int64_t rows, int dim) {
   if (rows <= 0) return hipSuccess;
-  if (dim & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gather_add_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, idx, table, tidx, dst, rows,
-                     dim >> 2);
+  if ((dim & 3) || (lds & 3) || (ldt & 3) || (ldd & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_add_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, lds >> 2, idx, table, ldt >> 2,
+                     tidx, dst, ldd >> 2, rows, dim >> 2);
   return hipGetLastError();
 }
 

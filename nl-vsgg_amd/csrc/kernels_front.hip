@@ -108,13 +108,12 @@ __global__ void __launch_bounds__(256)
 objcls_prep_kernel(const float* __restrict__ features, const float* __restrict__ dist,
                    const float* __restrict__ boxes, const float* __restrict__ E0,
                    const float* __restrict__ pos_scale, const float* __restrict__ pos_shift,
-                   const float* __restrict__ pos_w, const float* __restrict__ pos_b, float* __restrict__ z, int B,
-                   int feat_dim, int ncls, int emb_dim) {
+                   const float* __restrict__ pos_w, const float* __restrict__ pos_b, float* __restrict__ z,
+                   int64_t ldz, int B, int feat_dim, int ncls, int emb_dim) {
   __shared__ float d[64];
   __shared__ float cs[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int zd = feat_dim + emb_dim + 128;
-  float* zr = z + (int64_t)b * zd;
+  float* zr = z + (int64_t)b * ldz;
   if (tid < ncls) d[tid] = dist[(int64_t)b * ncls + tid];
   if (tid == 0) {
     const float* bx = boxes + (int64_t)b * 5 + 1;
@@ -139,10 +138,10 @@ objcls_prep_kernel(const float* __restrict__ features, const float* __restrict__
 
 hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,
                               const float* E0, const float* pos_scale, const float* pos_shift, const float* pos_w,
-                              const float* pos_b, float* z, int B, int feat_dim, int ncls, int emb_dim) {
-  if (ncls > 64) return hipErrorInvalidValue;
+                              const float* pos_b, float* z, int64_t ldz, int B, int feat_dim, int ncls, int emb_dim) {
+  if (ncls > 64 || ldz < feat_dim + emb_dim + 128) return hipErrorInvalidValue;
   hipLaunchKernelGGL(objcls_prep_kernel, dim3(B), dim3(256), 0, s, features, dist, boxes, E0, pos_scale,
-                     pos_shift, pos_w, pos_b, z, B, feat_dim, ncls, emb_dim);
+                     pos_shift, pos_w, pos_b, z, ldz, B, feat_dim, ncls, emb_dim);
   return hipGetLastError();
 }
 

@@ -23,13 +23,13 @@ static const TileInfo kTiles[TILE_COUNT] = {
     {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
     {128, 256, 0.80f, 1}};   // last: TILE_UNION (never chosen by plan_gemm)
 
-static int num_cus() {
-  static int n = 0;
+int num_cus() {
+  static int cus[kMaxDevices] = {};
+  const int dev = current_device();
+  int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
   if (!n) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
   }
   return n;
 }
@@ -92,13 +92,11 @@ size_t gemm_slab_floats_max() {
 template <class T, class Epi, int PIPE>
 static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
                                 int K, float* slab, const Epi& epi) {
-  static bool attr_set = false;
+  static DeviceMarks marks;
   auto kern = gemm_sk_kernel<T, Epi, PIPE>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
   const int ksteps = (K + kBK - 1) / kBK;

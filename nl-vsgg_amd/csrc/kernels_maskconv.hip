@@ -163,17 +163,11 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
 hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w0p, const float* bias,
                                   const float* scale, const float* shift, float* c2, int P) {
   if (P <= 0) return hipSuccess;
-  static bool configured = false;
+  static DeviceMarks marks;
   constexpr int lds_bytes = kMcLdsFloats * 4;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mask_conv1_pool_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
-  int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const int grid = std::min(P, 2 * std::max(ncu, 1));
+  hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(mask_conv1_pool_kernel), lds_bytes);
+  if (e != hipSuccess) return e;
+  const int grid = std::min(P, 2 * std::max(num_cus(), 1));
   hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, w0p, bias, scale, shift, c2, P);
   return hipGetLastError();
 }

@@ -36,8 +36,8 @@ struct DevBuf {
   hipError_t ensure(size_t need) {
     if (need <= bytes) return hipSuccess;
     if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
-    // 256 bytes of slack and zero-initialised: GEMM A operands are read up to pad32(K) columns per row, i.e. up to
-    // 124 bytes past the last row, and what is read there must be finite (it is multiplied by zero-padded weights)
+    // zero-initialised, 256 bytes of slack: the pad columns of the activation rows (row stride pad32(D)) must be zero
+    // and stay zero -- the GEMM A loader reads them for the K tail -- and clamped loads may touch the slack
     need = ((need + 255) & ~size_t(255)) + 256;
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) return e;
@@ -246,30 +246,31 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
                       const int* seq_off, const int* seq_len, int nseq, int maxlen) {
   const SttranConfig& c = h->cfg;
   const int D = c.embed_dim, F = c.ffn_dim;
+  const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (xin / xout included)
   float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
   float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>();
   int rc;
-  if ((rc = run_linear(h, s, GemmOperand{xin, D, nullptr}, W(h, p + ".self_attn.in_proj_weight"), M, 3 * D, D,
+  if ((rc = run_linear(h, s, GemmOperand{xin, LD, nullptr}, W(h, p + ".self_attn.in_proj_weight"), M, 3 * D, D,
                        epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
   {
     ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * M * maxlen * D, 4.0 * M * 4 * D);
-    HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, D, c.nhead));
+    HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, LD, D, c.nhead));
   }
-  EpiLinear eo = epi_plain(Y, D, W(h, p + ".self_attn.out_proj.bias"));
-  eo.res = xin; eo.ldres = D;
-  if ((rc = run_linear(h, s, GemmOperand{ATT, D, nullptr}, W(h, p + ".self_attn.out_proj.weight"), M, D, D, eo))) return rc;
+  EpiLinear eo = epi_plain(Y, LD, W(h, p + ".self_attn.out_proj.bias"));
+  eo.res = xin; eo.ldres = LD;
+  if ((rc = run_linear(h, s, GemmOperand{ATT, LD, nullptr}, W(h, p + ".self_attn.out_proj.weight"), M, D, D, eo))) return rc;
   {
     ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
-    HIPCK(launch_layernorm(s, Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, M, D));
+    HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, LD, M, D));
   }
-  if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
-                       epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
-  EpiLinear e2 = epi_plain(Y, D, W(h, p + ".linear2.bias"));
-  e2.res = H; e2.ldres = D;
-  if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2))) return rc;
+  if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
+                       epi_plain(F1, LF, W(h, p + ".linear1.bias"), 1)))) return rc;
+  EpiLinear e2 = epi_plain(Y, LD, W(h, p + ".linear2.bias"));
+  e2.res = H; e2.ldres = LD;
+  if ((rc = run_linear(h, s, GemmOperand{F1, LF, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2))) return rc;
   {
     ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
-    HIPCK(launch_layernorm(s, Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, M, D));
+    HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, LD, M, D));
   }
   return STTRAN_OK;
 }
@@ -278,26 +279,30 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   if (P <= h->capP && B <= h->capB) return STTRAN_OK;
   HIPCK(hipDeviceSynchronize());
   const int64_t cp = std::max(P, h->capP), cb = std::max(B, h->capB);
-  const int64_t D = h->cfg.embed_dim, F = h->cfg.ffn_dim, tok = 2 * cp;
+  // Every [rows, D] activation buffer has a row stride of LD = pad32(D) floats (1952 for D = 1936): rows start on
+  // 128-byte lines, and the 16 pad columns -- zeroed here, never written by any kernel -- are what the GEMM A loader
+  // reads for the K tail (B_KMAJOR_PAD), so nothing a previous call left behind can reach a later call's result.
+  const int64_t D = h->cfg.embed_dim, LD = pad32(D), F = h->cfg.ffn_dim, tok = 2 * cp;
   HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
-  HIPCK(h->x0.ensure((size_t)cp * D * 4));
-  HIPCK(h->ebuf.ensure((size_t)cp * D * 4));
+  HIPCK(h->x0.ensure((size_t)cp * LD * 4));
+  HIPCK(h->ebuf.ensure((size_t)cp * LD * 4));
   HIPCK(h->qkv.ensure((size_t)tok * 3 * D * 4));
-  HIPCK(h->att.ensure((size_t)tok * D * 4));
-  HIPCK(h->ybuf.ensure((size_t)tok * D * 4));
-  HIPCK(h->hbuf.ensure((size_t)tok * D * 4));
-  HIPCK(h->f1.ensure((size_t)tok * F * 4));
-  HIPCK(h->gbuf.ensure((size_t)tok * D * 4));
-  HIPCK(h->uni.ensure((size_t)(cp + tok) * D * 4));
+  HIPCK(h->att.ensure((size_t)tok * LD * 4));
+  HIPCK(h->ybuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->hbuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->f1.ensure((size_t)tok * pad32(F) * 4));
+  HIPCK(h->gbuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->uni.ensure((size_t)(cp + tok) * LD * 4));
   HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
   HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
   HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + (size_t)cp * 2 * 4 + 4096));
   if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
-    HIPCK(h->zbuf.ensure((size_t)cb * (h->cfg.feat_dim + 328) * 4));
+    HIPCK(h->zbuf.ensure((size_t)cb * pad32(h->cfg.feat_dim + 328) * 4));
     HIPCK(h->hobj.ensure((size_t)cb * 1024 * 4));
   }
   h->capP = cp;
   h->capB = cb;
+  h->cached_P = -1;     // the index buffer may have been re-allocated (and zeroed): the cached layout is gone
   return STTRAN_OK;
 }
 
@@ -716,6 +721,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
   if (is_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips)) {
     std::vector<int32_t> buf;
+    h->cached_P = -1;      // h->lay is about to change: the cache only becomes valid again once the upload is enqueued
     if (is_dsg) {
       // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
       // second model on the shared kernels, not the latency path
@@ -760,6 +766,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   int* obj_idx = subj_idx + h->capP;
 
   const int D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
+  const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (ensure_workspace)
   float* X0 = h->x0.as<float>();
   float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
   float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>(); float* G = h->gbuf.as<float>();
@@ -770,15 +777,16 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   if (oc) {
     float* Z = h->zbuf.as<float>(); float* HO = h->hobj.as<float>();
     const int zd = FD + 200 + 128;
+    const int64_t ldz = pad32(zd);
     {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * B * (2.0 * zd));
       HIPCK(launch_objcls_prep(s, in->features, in->distribution, in->boxes, W(h, "object_classifier.obj_embed.weight"),
                                h->oc_pos_scale, h->oc_pos_shift, W(h, "object_classifier.pos_embed.1.weight"),
-                               W(h, "object_classifier.pos_embed.1.bias"), Z, (int)B, FD, NC - 1, 200));
+                               W(h, "object_classifier.pos_embed.1.bias"), Z, ldz, (int)B, FD, NC - 1, 200));
     }
     EpiLinear e1 = epi_plain(HO, 1024, W(h, "object_classifier.decoder_lin.0.bias"), 1);
     e1.scale = h->oc_bn_scale; e1.shift = h->oc_bn_shift;     // Linear -> BN -> ReLU
-    if ((rc = run_linear(h, s, GemmOperand{Z, zd, nullptr}, W(h, "object_classifier.decoder_lin.0.weight"), (int)B, 1024, zd, e1))) return rc;
+    if ((rc = run_linear(h, s, GemmOperand{Z, ldz, nullptr}, W(h, "object_classifier.decoder_lin.0.weight"), (int)B, 1024, zd, e1))) return rc;
     EpiLinear e2 = epi_plain(out->distribution, NC, W(h, "object_classifier.decoder_lin.3.bias"));
     if ((rc = run_linear(h, s, GemmOperand{HO, 1024, nullptr}, W(h, "object_classifier.decoder_lin.3.weight"), (int)B, NC, 1024, e2))) return rc;
   }
@@ -787,12 +795,12 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   {
     ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2);
     HIPCK(launch_pair_prep(s, in->pair_idx, in->labels, (int)P, (int)B, NC, W(h, "obj_embed.weight"),
-                           W(h, "obj_embed2.weight"), 200, subj_idx, obj_idx, X0, D, 1536, h->err_flag));
+                           W(h, "obj_embed2.weight"), 200, subj_idx, obj_idx, X0, (int)LD, 1536, h->err_flag));
   }
   if ((rc = run_linear(h, s, GemmOperand{in->features, FD, subj_idx}, W(h, "subj_fc.weight"), (int)P, 512, FD,
-                       epi_plain(X0, D, W(h, "subj_fc.bias"))))) return rc;
+                       epi_plain(X0, LD, W(h, "subj_fc.bias"))))) return rc;
   if ((rc = run_linear(h, s, GemmOperand{in->features, FD, obj_idx}, W(h, "obj_fc.weight"), (int)P, 512, FD,
-                       epi_plain(X0 + 512, D, W(h, "obj_fc.bias"))))) return rc;
+                       epi_plain(X0 + 512, LD, W(h, "obj_fc.bias"))))) return rc;
   {
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
     {
@@ -811,9 +819,12 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                             h->slab.as<float>()));
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
-                       epi_plain(X0 + 1024, D, W(h, "vr_fc.bias"))))) return rc;
-  if (out->rel_features_tap)
-    HIPCK(hipMemcpyAsync(out->rel_features_tap, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+                       epi_plain(X0 + 1024, LD, W(h, "vr_fc.bias"))))) return rc;
+  // taps are dense [P, D] caller buffers
+  auto tap = [&](float* dst, const float* src) {
+    return hipMemcpy2DAsync(dst, (size_t)D * 4, src, (size_t)LD * 4, (size_t)D * 4, (size_t)P, hipMemcpyDeviceToDevice, s);
+  };
+  if (out->rel_features_tap) HIPCK(tap(out->rel_features_tap, X0));
 
   // ---- spatial encoder, one sequence per non-empty frame (lib/transformer.py:20-30,144) --------
   const bool dsg = c.model == STTRAN_MODEL_DSG_DETR;
@@ -826,19 +837,18 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     if ((rc = run_encoder_layer(h, s, p, xin, xout, (int)P, enc_off, enc_len, L.n_enc_seq, L.max_enc))) return rc;
     xin = xout;
   }
-  if (n_enc_layers == 0) HIPCK(hipMemcpyAsync(UNI, X0, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
-  if (out->local_output_tap)
-    HIPCK(hipMemcpyAsync(out->local_output_tap, UNI, (size_t)P * D * 4, hipMemcpyDeviceToDevice, s));
+  if (n_enc_layers == 0) HIPCK(hipMemcpyAsync(UNI, X0, (size_t)P * LD * 4, hipMemcpyDeviceToDevice, s));
+  if (out->local_output_tap) HIPCK(tap(out->local_output_tap, UNI));
 
   const int NT = (int)L.n_dec_tok, NN = (int)L.n_need;
-  float* UDEC = UNI + (size_t)P * D;
+  float* UDEC = UNI + (size_t)P * LD;
   if (dsg) {
     // ---- DSG-DETR temporal encoder (lib/dsg_detr.py:545-564): one sequence per object class over the
     //      whole clip, sinusoidal PE by the pair's frame rank inside its sequence, 3 encoder layers.
     //      dec_src = pair of each sequence token, need = its PE row, dec_off/len = class sequences.
     {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 12.0 * P * D);
-      HIPCK(launch_gather_add_rows(s, UNI, dec_src, W(h, "positional_encoder.pe"), need, G, P, D));
+      HIPCK(launch_gather_add_rows(s, UNI, LD, dec_src, W(h, "positional_encoder.pe"), D, need, G, LD, P, D));
     }
     const float* gin = G;
     for (int i = 0; i < 3; ++i) {
@@ -852,7 +862,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   if (NT > 0 && c.dec_layers > 0) {
     {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D);
-      HIPCK(launch_gather_rows(s, UNI, dec_src, G, NT, D));
+      HIPCK(launch_gather_rows(s, UNI, LD, dec_src, G, LD, NT, D));
     }
     for (int i = 0; i < c.dec_layers; ++i) {
       const std::string p = "glocal_transformer.global_attention.layers." + std::to_string(i);
@@ -871,44 +881,44 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
         eq.out_rowidx = tok0; eq.out_rowidx2 = tok1;
-        if ((rc = run_linear(h, s, GemmOperand{UNI, D, nullptr}, Win, (int)P, 3 * D, D, eq))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{UNI, LD, nullptr}, Win, (int)P, 3 * D, D, eq))) return rc;
       } else if (!last) {
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = 2 * D; eq.rb_ld = 2 * D;
-        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win, NT, 3 * D, D, eq))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{G, LD, nullptr}, Win, NT, 3 * D, D, eq))) return rc;
       } else {
         EpiLinear ekv = epi_plain(QKV + D, 3 * D, bin + D);                 // k | v columns, all tokens
         ekv.rowbias = h->dec[i].posbias + D; ekv.rowslot = slot; ekv.rb_cols = D; ekv.rb_ld = 2 * D;
-        if ((rc = run_linear(h, s, GemmOperand{G, D, nullptr}, Win + (size_t)D * pad32(D), NT, 2 * D, D, ekv))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{G, LD, nullptr}, Win + (size_t)D * pad32(D), NT, 2 * D, D, ekv))) return rc;
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);                          // q columns, needed rows only
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = D; eq.rb_ld = 2 * D;
         eq.out_rowidx = need;
-        if ((rc = run_linear(h, s, GemmOperand{G, D, need}, Win, NN, D, D, eq))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{G, LD, need}, Win, NN, D, D, eq))) return rc;
       }
       {
         ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * MQ * L.max_dec * D, 4.0 * (MQ * 2.0 + NT * 2.0) * D);
-        HIPCK(launch_attention(s, QKV, dec_off, dec_len, last ? qbegin : nullptr, L.n_dec_seq, L.max_dec, ATT, D,
+        HIPCK(launch_attention(s, QKV, dec_off, dec_len, last ? qbegin : nullptr, L.n_dec_seq, L.max_dec, ATT, LD, D,
                                c.nhead));
       }
-      EpiLinear eo = epi_plain(Y, D, W(h, p + ".multihead2.out_proj.bias"));
-      eo.res = G; eo.ldres = D; eo.res_rowidx = rows;
-      if ((rc = run_linear(h, s, GemmOperand{ATT, D, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
+      EpiLinear eo = epi_plain(Y, LD, W(h, p + ".multihead2.out_proj.bias"));
+      eo.res = G; eo.ldres = LD; eo.res_rowidx = rows;
+      if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
       {
         ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D);
-        HIPCK(launch_layernorm(s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, MQ, D));
+        HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, LD, MQ, D));
       }
-      if ((rc = run_linear(h, s, GemmOperand{H, D, nullptr}, W(h, p + ".linear1.weight"), MQ, F, D,
-                           epi_plain(F1, F, W(h, p + ".linear1.bias"), 1)))) return rc;
-      EpiLinear e2 = epi_plain(last ? UDEC : G, D, W(h, p + ".linear2.bias"));
-      e2.res = H; e2.ldres = D;
-      if ((rc = run_linear(h, s, GemmOperand{F1, F, nullptr}, W(h, p + ".linear2.weight"), MQ, D, F, e2))) return rc;
+      if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), MQ, F, D,
+                           epi_plain(F1, LF, W(h, p + ".linear1.bias"), 1)))) return rc;
+      EpiLinear e2 = epi_plain(last ? UDEC : G, LD, W(h, p + ".linear2.bias"));
+      e2.res = H; e2.ldres = LD;
+      if ((rc = run_linear(h, s, GemmOperand{F1, LF, nullptr}, W(h, p + ".linear2.weight"), MQ, D, F, e2))) return rc;
     }
   } else if (NT > 0) {
     // dec_layers == 0: windows pass through -- the needed rows are encoder rows
-    HIPCK(launch_gather_rows(s, UNI, dec_src, G, NT, D));
-    HIPCK(launch_gather_rows(s, G, need, UDEC, NN, D));
+    HIPCK(launch_gather_rows(s, UNI, LD, dec_src, G, LD, NT, D));
+    HIPCK(launch_gather_rows(s, G, LD, need, UDEC, LD, NN, D));
   }
-  if (out->global_output_tap) HIPCK(launch_gather_rows(s, UNI, out_src, out->global_output_tap, P, D));
+  if (out->global_output_tap) HIPCK(launch_gather_rows(s, UNI, LD, out_src, out->global_output_tap, D, P, D));
 
   // ---- relation heads on the 'latter' rows (lib/sttran.py:404-409, lib/transformer.py:179-185) --
   {
@@ -917,7 +927,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                 c.attention_classes, c.spatial_classes, c.contact_classes};
     GemmPlan plan = plan_gemm(P, nh, D, TILE_64x64, 1);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D));
-    HIPCK(gemm_heads(s, GemmOperand{UNI, D, out_src}, GemmOperand{h->heads_w, pad32(D), nullptr}, (int)P, nh, D, eh, plan,
+    HIPCK(gemm_heads(s, GemmOperand{UNI, LD, out_src}, GemmOperand{h->heads_w, pad32(D), nullptr}, (int)P, nh, D, eh, plan,
                      h->slab.as<float>()));
   }
   if (h->prof_on) h->prof.forwards += 1;
@@ -1029,7 +1039,7 @@ int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
 int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
                            int64_t dim, void* stream) {
   if (!x || !gamma || !beta || !y) return STTRAN_ERR_INVALID;
-  return launch_layernorm(reinterpret_cast<hipStream_t>(stream), x, gamma, beta, y, rows, (int)dim) == hipSuccess
+  return launch_layernorm(reinterpret_cast<hipStream_t>(stream), x, dim, gamma, beta, y, dim, rows, (int)dim) == hipSuccess
              ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
@@ -1038,7 +1048,7 @@ int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32
   (void)tokens;
   if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
   return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, nullptr, num_seq, max_len, out, dim,
-                          nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+                          dim, nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
 }  // extern "C"

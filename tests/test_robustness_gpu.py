@@ -1,0 +1,119 @@
+"""State that survives between calls on one handle must never change a later call's result:
+stale workspace contents (a NaN clip followed by a smaller clean clip), the cached index maps
+(workspace growth, a failed call in between) and per-device launch state (two handles on two GPUs)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+
+OUT_KEYS = ("attention_distribution", "spatial_distribution", "contacting_distribution")
+CLASSES = ["__background__"] + [f"c{i}" for i in range(36)]
+
+
+def _model(sd, device="cuda:0"):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.sttran import STTran
+    m = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES,
+               enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(device)
+    m.eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    return m
+
+
+def _cuda_entry(e, device="cuda:0"):
+    return {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) and k != "frame_counts" else v)
+            for k, v in e.items()}
+
+
+def _run(m, e, device="cuda:0"):
+    p = m(_cuda_entry(e, device))
+    torch.cuda.synchronize()
+    return {k: p[k].cpu().numpy() for k in OUT_KEYS}
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return syn.make_sttran_state_dict(7)
+
+
+@pytest.mark.parametrize("poison", ["features", "union_feat", "spatial_masks"])
+def test_nan_clip_does_not_contaminate_later_calls(poison, weights):
+    """A clip with non-finite inputs (a corrupt feature file) gives non-finite outputs -- and nothing else.
+    The next, smaller clip on the same handle must equal, bit for bit, its result on a fresh handle: the
+    GEMM A loader reads 16 floats past column 1936 of every activation row (the K tail, multiplied by
+    zero-padded weights), which must never be another call's leftovers."""
+    big = syn.make_entry(301, [6, 5, 7, 6, 4])
+    small = syn.make_entry(302, [2, 3, 1])
+    clean = _run(_model(weights), small)
+    m = _model(weights)
+    bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in big.items()}
+    bad[poison] = bad[poison].copy()
+    bad[poison][...] = np.nan
+    out = _run(m, bad)
+    assert not np.isfinite(out["attention_distribution"]).any()
+    again = _run(m, small)
+    for k in OUT_KEYS:
+        assert np.isfinite(again[k]).all(), k
+        np.testing.assert_array_equal(again[k], clean[k], err_msg=k)
+    # and with Inf left behind by a second poisoned call of yet another size
+    bad2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in syn.make_entry(303, [3, 3, 3, 3]).items()}
+    bad2[poison] = np.full_like(bad2[poison], np.inf)
+    _run(m, bad2)
+    again = _run(m, small)
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(again[k], clean[k], err_msg=k)
+
+
+def test_reserve_between_forwards_keeps_results(weights):
+    """forward -> reserve(larger) -> forward of the same clip: growing the workspace re-allocates (and zeroes) the
+    device index buffer, so the cached layout must be rebuilt, not trusted."""
+    e = syn.make_entry(311, [3, 1, 4, 2, 2])
+    m = _model(weights)
+    a = _run(m, e)
+    m.reserve(5000, 6000)
+    b = _run(m, e)
+    m.reserve(20000, 24000)
+    c = _run(m, e)
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(a[k], c[k], err_msg=k)
+
+
+def test_failed_forward_does_not_poison_layout_cache(weights):
+    """forward(A) ok, forward(B) fails after its layout was built (a 600-token window: STTRAN_ERR_LIMIT),
+    forward(A) again: must not run A's device index maps with B's host-side offsets."""
+    from nl_vsgg_amd._native import SttranError
+    A = syn.make_entry(321, [4, 2, 5, 3])
+    m = _model(weights)
+    a = _run(m, A)
+    with pytest.raises(SttranError) as ei:
+        m(_cuda_entry(syn.make_entry(322, [300, 300])))
+    assert ei.value.code == 6
+    b = _run(m, A)
+    bad = dict(_cuda_entry(A)); bad["frame_counts"] = np.array([4, 2, 5, 4], dtype=np.int32)   # sums to 15 != 14
+    with pytest.raises(SttranError):
+        m(bad)
+    c = _run(m, A)
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(a[k], c[k], err_msg=k)
+
+
+def test_two_handles_on_two_devices(weights):
+    """sttran_create accepts any device ordinal: the > 64 KB dynamic-LDS limits and the CU count the tile planner
+    uses are per-device state (a process-wide 'already configured' flag would skip device 1)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    e = syn.make_entry(331, [5, 3, 6, 2])
+    a = _run(_model(weights, "cuda:0"), e, "cuda:0")
+    with torch.cuda.device(1):
+        m1 = _model(weights, "cuda:1")
+        p = m1(_cuda_entry(e, "cuda:1"))
+        torch.cuda.synchronize(1)
+        b = {k: p[k].cpu().numpy() for k in OUT_KEYS}
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
