@@ -140,6 +140,8 @@ def main():
                        obj_classes=CLASSES, enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True,
                        feat_dim=2048).to(device)
     model.eval()
+    model.check_indices = False      # enqueue-only: no per-call synchronisation inside the timed region
+    model.strict_inputs = True       # a hidden per-step copy of the inputs would be timed as compute
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -164,7 +166,8 @@ def main():
     turn = [0]
 
     def step():
-        pred = model(batch)
+        # a fresh dict per call: forward() writes its outputs into the entry (sgdet replaces `distribution`)
+        pred = model(dict(batch))
         if world > 1:
             k = turn[0]
             if inflight[k] is not None:
@@ -234,18 +237,18 @@ def main():
     if cps > 1 and world == 1:
         one = clips[0]
         for _ in range(3):
-            model(one)
+            model(dict(one))
         torch.cuda.synchronize()
         n1 = max(2 * args.steps, 20)
         t0 = time.perf_counter()
         for _ in range(n1):
-            model(one)
+            model(dict(one))
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / n1
         result["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1,
                                        "note": "same clip shape with clips_per_step = 1 (latency-bound: one clip cannot "
                                                "fill 256 CUs)"}
-        model(batch)                                    # restore the cached layout of the batch
+        model(dict(batch))                              # restore the cached layout of the batch
 
     # ---- PCIe-inclusive rate (never `value`): inputs start in pinned host memory each step ----------
     if args.pcie and world == 1:

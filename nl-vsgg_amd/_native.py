@@ -106,6 +106,10 @@ class SttranError(RuntimeError):
         self.code = code
 
 
+class SttranIndexError(SttranError, IndexError):
+    """pair_idx / labels out of range: what torch raises as an IndexError at lib/sttran.py:381-393."""
+
+
 def load():
     """Load libsttran_hip.so and bind every declared symbol.  Raises if the library is absent:
     the product path has no other implementation to fall back to."""

@@ -29,6 +29,11 @@ namespace sttran {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// torch.relu and torch's max_pool2d propagate NaN; fmaxf / v_max_f32 return the other operand.  A clip with a
+// non-finite input must come out non-finite (as it does from the reference), not silently cleaned.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a < b || b != b) ? b : a; }
+
 constexpr int kBK = 32;        // K-step
 constexpr int kLdsStride = 36; // dwords per staged row (32 + 4 pad)
 
@@ -80,7 +85,7 @@ struct EpiLinear {
   __device__ __forceinline__ void put(int orow, int row, int col, float v) const {
     if (rowbias && col < rb_cols) v += rowbias[(int)rowslot[orow] * rb_ld + col];
     if (scale) v = v * scale[col] + shift[col];
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu) v = relu_nan(v);
     if (res) v += res[(int64_t)(res_rowidx ? res_rowidx[row] : row) * ldres + col];
     C[(int64_t)orow * ldc + col] = v;
   }
@@ -115,7 +120,7 @@ struct EpiHeads {
 struct EpiConvRelBn {
   float* V; const float* bias; const float* scale; const float* shift; int C; int HW;
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    v = fmaxf(v + bias[row], 0.f) * scale[row] + shift[row];
+    v = relu_nan(v + bias[row]) * scale[row] + shift[row];
     int p = col / HW, hw = col - p * HW;
     V[((int64_t)p * C + row) * HW + hw] = v;
   }

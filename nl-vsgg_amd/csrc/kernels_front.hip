@@ -132,7 +132,7 @@ objcls_prep_kernel(const float* __restrict__ features, const float* __restrict__
   if (tid < 128) {
     float a = pos_b[tid];
     for (int i = 0; i < 4; ++i) a = fmaf(pos_w[tid * 4 + i], cs[i], a);
-    zr[feat_dim + emb_dim + tid] = fmaxf(a, 0.f);
+    zr[feat_dim + emb_dim + tid] = relu_nan(a);
   }
 }
 

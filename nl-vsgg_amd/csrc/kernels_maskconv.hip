@@ -126,7 +126,7 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
         if (n < 196) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pool[(r + 4 * fh) * 196 + n] = fmaxf(acc[j][4 * q + r] + cb[r], 0.f) * cs[r] + ct[r];
+            pool[(r + 4 * fh) * 196 + n] = relu_nan(acc[j][4 * q + r] + cb[r]) * cs[r] + ct[r];
         }
       }
       __syncthreads();
@@ -136,10 +136,10 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
         if (o < kMcPoolCh * 49) {
           const float* s = pool + pbase[i];
           const bool up = (pmask >> (2 * i)) & 1u, left = (pmask >> (2 * i + 1)) & 1u;
-          float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[14], s[15]));
-          if (left) m = fmaxf(m, fmaxf(s[-1], s[13]));
-          if (up) m = fmaxf(m, fmaxf(s[-14], s[-13]));
-          if (up && left) m = fmaxf(m, s[-15]);
+          float m = max_nan(max_nan(s[0], s[1]), max_nan(s[14], s[15]));
+          if (left) m = max_nan(m, max_nan(s[-1], s[13]));
+          if (up) m = max_nan(m, max_nan(s[-14], s[-13]));
+          if (up && left) m = max_nan(m, s[-15]);
           dst[q * kMcPoolCh + pdst[i]] = m;
         }
       }

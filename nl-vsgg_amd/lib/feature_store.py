@@ -19,10 +19,16 @@ import torch
 def save_frame_features(frame_dir, classes, confs, rects, feats):
     """Writer in the reference's format (for tests and for producing fixtures)."""
     os.makedirs(frame_dir, exist_ok=True)
-    per_box = [{"class": c, "conf": s, "rect": np.asarray(r, dtype=np.float32)}
-               for c, s, r in zip(classes, confs, rects)]
-    np.save(os.path.join(frame_dir, "dets.npy"), np.array(per_box, dtype=object), allow_pickle=True)
-    np.save(os.path.join(frame_dir, "feat.npy"), np.asarray(feats, dtype=np.float32))
+    # same statement and field types as extract_bbox_features_ag.py:113-120: a LIST of dicts (numpy builds the object
+    # array; an empty list becomes a float64 array of shape (0,)) with numpy-scalar class / conf and a float32[4] rect
+    cls_info, conf_info = np.asarray(classes, dtype=np.int64), np.asarray(confs, dtype=np.float32)
+    bbox_info = np.asarray(rects, dtype=np.float32).reshape(-1, 4)
+    per_box = [{"class": cls_info[i], "conf": conf_info[i], "rect": bbox_info[i]} for i in range(len(cls_info))]
+    np.save(os.path.join(frame_dir, "dets.npy"), per_box, allow_pickle=True)
+    feat_info = np.asarray(feats, dtype=np.float32)
+    if feat_info.ndim != 2:                                     # e.g. an empty python list for a frame without boxes
+        feat_info = feat_info.reshape(len(per_box), -1) if len(per_box) else np.zeros((0, 2048), dtype=np.float32)
+    np.save(os.path.join(frame_dir, "feat.npy"), feat_info)
 
 
 def read_frame(frame_dir):
@@ -82,11 +88,18 @@ class ClipFeatureLoader:
         if self._stream is None:
             out["features"], out["boxes"] = feats.clone(), boxes.clone()
             return out
+        consumer = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._stream):
             out["features"] = feats.to(self.device, non_blocking=True)
             out["boxes"] = boxes.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._stream)
+        # The two device tensors were allocated from the side stream's pool.  Tell the caching allocator that the
+        # consumer's stream uses them too: otherwise, once the consumer drops them while its (asynchronously enqueued)
+        # forward is still running, the next load() could be handed the same block and overwrite it under that forward.
+        # A consumer that works on another stream than the one current at load() time must call record_stream itself.
+        out["features"].record_stream(consumer)
+        out["boxes"].record_stream(consumer)
         self._ev[k] = ev
         out["ready"] = ev        # consumer: torch.cuda.current_stream().wait_event(out['ready'])
         return out

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import warnings
 
 import numpy as np
 import torch
@@ -62,7 +63,17 @@ class STTran:
         self.feat_dim = int(feat_dim)
         self.training = False
         self.taps = False               # parity tests: also return stage tensors
-        self.check_indices = False      # synchronise and validate pair_idx/labels after each call
+        # check_indices (default True = the reference's behaviour): out-of-range `pair_idx` / `labels` raise an
+        # IndexError like the torch indexing at lib/sttran.py:381-393 does.  The kernels clamp and set a device flag;
+        # reading it costs one stream synchronisation per call, which the reference's own loop pays anyway (it
+        # synchronises several times per frame, lib/transformer.py:138-140).  Throughput pipelines that only enqueue
+        # (bench.py, tools/ag_split_bench.py, HIP-graph capture) set it to False and call `sync_check()` when they like.
+        self.check_indices = True
+        # strict_inputs: raise instead of silently converting an input that is not already a contiguous tensor of
+        # the expected dtype on this model's device (torch would accept it; here a conversion is a hidden copy --
+        # 0.9 GB for `union_feat` at 64x36 -- on every call).  Off: convert, and warn once per key for copies > 16 MB.
+        self.strict_inputs = False
+        self._warned = set()
         self._device = None
         self._handle = None
         self._sd = {}
@@ -179,13 +190,36 @@ class STTran:
         nat.check(self._lib, self._handle, self._lib.sttran_reserve(self._handle, int(max_pairs), int(max_boxes)))
 
     # ---- forward ---------------------------------------------------------------------------------
-    def _dev(self, t, dtype):
+    def _dev(self, t, dtype, key="?"):
+        dev = torch.device("cuda", self._device)
+        ok = isinstance(t, torch.Tensor) and t.device == dev and t.dtype == dtype and t.is_contiguous()
+        if ok:
+            return t
+        if self.strict_inputs:
+            what = (f"{tuple(t.shape)} {t.dtype} on {t.device}, contiguous={t.is_contiguous()}"
+                    if isinstance(t, torch.Tensor) else type(t).__name__)
+            raise ValueError(f"entry[{key!r}] must be a contiguous {dtype} tensor on {dev} (got {what}); "
+                             f"strict_inputs=True refuses the hidden copy")
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t))
-        dev = torch.device("cuda", self._device)
+        nbytes = t.numel() * t.element_size()
+        if nbytes > (16 << 20) and key not in self._warned:
+            self._warned.add(key)
+            warnings.warn(f"STTran: entry[{key!r}] ({nbytes >> 20} MiB) is copied on every call because it is not a "
+                          f"contiguous {dtype} tensor on {dev}; fix the producer or set strict_inputs=True to catch it")
         if t.device != dev or t.dtype != dtype:
             t = t.to(device=dev, dtype=dtype)
         return t.contiguous()
+
+    def sync_check(self):
+        """Wait for the current stream and raise if a kernel met an out-of-range pair_idx / labels entry since the
+        last check (what `check_indices=True` does after every call)."""
+        stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
+        rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
+        if rc == 1:
+            msg = self._lib.sttran_last_error(self._handle) or b""
+            raise nat.SttranIndexError(rc, msg.decode("utf-8", "replace"))
+        nat.check(self._lib, self._handle, rc)
 
     def __call__(self, entry):
         return self.forward(entry)
@@ -197,19 +231,26 @@ class STTran:
         self._ensure_handle()
         lib, h = self._lib, self._handle
         f32, i64 = torch.float32, torch.int64
-        feats = self._dev(entry["features"], f32)
-        pair = self._dev(entry["pair_idx"], i64)
-        labels = self._dev(entry["labels"], i64)
-        union = self._dev(entry["union_feat"], f32)
-        masks = self._dev(entry["spatial_masks"], f32)
+        feats = self._dev(entry["features"], f32, "features")
+        pair = self._dev(entry["pair_idx"], i64, "pair_idx")
+        labels = self._dev(entry["labels"], i64, "labels")
+        union = self._dev(entry["union_feat"], f32, "union_feat")
+        masks = self._dev(entry["spatial_masks"], f32, "spatial_masks")
         P, B = int(pair.shape[0]), int(feats.shape[0])
         if P == 0:
             raise nat.SttranError(3, "entry has no pairs")
-        if union.shape[0] != P or masks.shape[0] != P or labels.shape[0] != B or feats.shape[1] != self.feat_dim:
-            raise ValueError("entry tensors disagree on the number of pairs / boxes")
+        # shapes the reference's layers would reject (nn.Linear / Conv2d / .view raise a RuntimeError there)
+        if (feats.dim() != 2 or feats.shape[1] != self.feat_dim or tuple(pair.shape) != (P, 2) or tuple(labels.shape) != (B,)
+                or tuple(union.shape) != (P, self.feat_dim, 7, 7) or tuple(masks.shape) != (P, 2, 27, 27)):
+            raise ValueError(
+                f"entry shapes: features {tuple(feats.shape)} (want [B,{self.feat_dim}]), pair_idx {tuple(pair.shape)} "
+                f"(want [P,2]), labels {tuple(labels.shape)} (want [B]), union_feat {tuple(union.shape)} (want "
+                f"[P,{self.feat_dim},7,7]), spatial_masks {tuple(masks.shape)} (want [P,2,27,27])")
         im = entry["im_idx"]
         im_dtype = nat.DTYPE_I64 if (isinstance(im, torch.Tensor) and not im.dtype.is_floating_point) else nat.DTYPE_F32
-        im = self._dev(im, i64 if im_dtype == nat.DTYPE_I64 else f32)
+        im = self._dev(im, i64 if im_dtype == nat.DTYPE_I64 else f32, "im_idx")
+        if tuple(im.shape) != (P,):
+            raise ValueError(f"entry['im_idx'] has shape {tuple(im.shape)}, want [{P}]")
         counts = _host_i32(entry.get("frame_counts"))
         clips = _host_i32(entry.get("clip_num_frames"))
         dev = feats.device
@@ -232,8 +273,16 @@ class STTran:
         out.contacting_distribution = con.data_ptr()
         keep = [feats, pair, labels, union, masks, im]
         if self.mode != "predcls":
-            boxes = self._dev(entry["boxes"], f32)
-            dist_in = self._dev(entry["distribution"], f32)
+            boxes = self._dev(entry["boxes"], f32, "boxes")
+            dist_in = self._dev(entry["distribution"], f32, "distribution")
+            # the reference multiplies distribution [B, C-1] with obj_embed.weight [C-1, 200] (lib/sttran.py:174) and
+            # would raise on anything else -- e.g. on an entry that already went through forward once, whose
+            # `distribution` now holds the [B, C] logits (:182)
+            if tuple(dist_in.shape) != (B, len(self.obj_classes) - 1) or tuple(boxes.shape) != (B, 5):
+                raise ValueError(f"entry['distribution'] {tuple(dist_in.shape)} / entry['boxes'] {tuple(boxes.shape)}: "
+                                 f"want [{B},{len(self.obj_classes) - 1}] and [{B},5] (was this entry already forwarded?)")
+            if "scores" not in entry or tuple(entry["scores"].shape) != (B,):
+                raise ValueError(f"entry['scores'] must be a [{B}] tensor in sgdet mode (lib/sttran.py:184)")
             dist_out = torch.empty((B, len(self.obj_classes)), dtype=f32, device=dev)
             inp.boxes, inp.distribution, out.distribution = boxes.data_ptr(), dist_in.data_ptr(), dist_out.data_ptr()
             keep += [boxes, dist_in]
@@ -245,7 +294,7 @@ class STTran:
         stream = torch.cuda.current_stream(dev).cuda_stream
         nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
         if self.check_indices:
-            nat.check(lib, h, lib.sttran_sync_check(h, C.c_void_p(stream)))
+            self.sync_check()
         # ---- the keys the reference writes (lib/sttran.py:91,182-184,404-409) ----
         entry["pred_labels"] = entry["labels"]
         if self.mode != "predcls":

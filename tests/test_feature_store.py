@@ -1,4 +1,6 @@
-"""dets.npy / feat.npy reader: round trip through the reference's on-disk format."""
+"""dets.npy / feat.npy reader: a committed fixture laid out the way the reference's writer lays it out
+(tests/golden/gen_feature_store_fixture.py restates extract_bbox_features_ag.py:113-120 type for type), plus round
+trips through this package's own writer."""
 import os
 
 import numpy as np
@@ -56,3 +58,53 @@ def test_loader_async_upload(tmp_path):
         torch.cuda.current_stream().wait_event(rec["ready"])
         got = rec["features"].cpu().numpy()
         np.testing.assert_array_equal(got, np.concatenate([r[3] for r in ref]))
+
+
+def _fixture(golden_dir):
+    root = os.path.join(golden_dir, "frame_features")
+    exp = np.load(os.path.join(root, "expected.npz"))
+    return root, exp, [str(f) for f in exp["frames"]]
+
+
+def test_reference_layout_fixture_read_like_the_reference_reads_it(golden_dir):
+    """lib/assign_pseudo_label.py:40-44: `np.load(dets_path, allow_pickle=True).tolist()` / `np.load(feat_path)`"""
+    root, exp, frames = _fixture(golden_dir)
+    for t, f in enumerate(frames):
+        dets = np.load(os.path.join(root, f, "dets.npy"), allow_pickle=True).tolist()
+        feat = np.load(os.path.join(root, f, "feat.npy"))
+        assert isinstance(dets, list) and len(dets) == len(exp[f"class_{t}"])
+        np.testing.assert_array_equal(feat, exp[f"feat_{t}"])
+        for i, d in enumerate(dets):
+            assert set(d) == {"class", "conf", "rect"}
+            assert isinstance(d["class"], np.int64) and isinstance(d["conf"], np.float32)      # numpy scalars, not python
+            assert d["rect"].dtype == np.float32 and d["rect"].shape == (4,)
+            assert d["class"] == exp[f"class_{t}"][i] and d["conf"] == exp[f"conf_{t}"][i]
+            np.testing.assert_array_equal(d["rect"], exp[f"rect_{t}"][i])
+
+
+def test_loader_returns_the_fixture_bytes(golden_dir):
+    """the loader on the reference-layout files (incl. the frame without detections, whose dets.npy is a float64
+    array of shape (0,) because numpy saw an empty list) returns exactly the stored values"""
+    root, exp, frames = _fixture(golden_dir)
+    rec = ClipFeatureLoader(device=None).load([os.path.join(root, f) for f in frames])
+    n = [len(exp[f"class_{t}"]) for t in range(len(frames))]
+    assert rec["boxes_per_frame"] == n and rec["num_frames"] == len(frames)
+    cat = lambda k: np.concatenate([exp[f"{k}_{t}"] for t in range(len(frames))])
+    assert rec["features"].numpy().tobytes() == cat("feat").tobytes()
+    assert rec["boxes"][:, 1:].numpy().tobytes() == cat("rect").tobytes()
+    np.testing.assert_array_equal(rec["boxes"][:, 0].numpy(), np.repeat(np.arange(len(frames)), n).astype(np.float32))
+    np.testing.assert_array_equal(rec["classes"].numpy(), cat("class"))
+    assert rec["scores"].numpy().tobytes() == cat("conf").tobytes()
+
+
+def test_own_writer_produces_the_reference_layout(tmp_path, golden_dir):
+    """save_frame_features is byte-compatible with the fixture for the same values"""
+    root, exp, frames = _fixture(golden_dir)
+    for t, f in enumerate(frames):
+        d = os.path.join(str(tmp_path), f)
+        save_frame_features(d, exp[f"class_{t}"], exp[f"conf_{t}"], exp[f"rect_{t}"], exp[f"feat_{t}"])
+        for name in ("dets.npy", "feat.npy"):
+            a = np.load(os.path.join(d, name), allow_pickle=True)
+            b = np.load(os.path.join(root, f, name), allow_pickle=True)
+            assert a.dtype == b.dtype and a.shape == b.shape, (f, name)
+        assert open(os.path.join(d, "feat.npy"), "rb").read() == open(os.path.join(root, f, "feat.npy"), "rb").read()

@@ -117,3 +117,65 @@ def test_two_handles_on_two_devices(weights):
         b = {k: p[k].cpu().numpy() for k in OUT_KEYS}
     for k in OUT_KEYS:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_strict_inputs_refuses_hidden_copy(weights):
+    """a non-contiguous / wrong-dtype / host tensor is converted (with a warning for big ones) by default and
+    refused under strict_inputs"""
+    e = _cuda_entry(syn.make_entry(341, [3, 2, 4]))
+    m = _model(weights)
+    ref = {k: m(dict(e))[k].cpu().numpy() for k in OUT_KEYS}
+    nc = dict(e)
+    nc["union_feat"] = e["union_feat"].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)     # same values, NHWC strides
+    assert not nc["union_feat"].is_contiguous()
+    got = m(dict(nc))
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k])
+    m.strict_inputs = True
+    with pytest.raises(ValueError, match="union_feat"):
+        m(dict(nc))
+    host = dict(e); host["features"] = e["features"].cpu()
+    with pytest.raises(ValueError, match="features"):
+        m(host)
+    dbl = dict(e); dbl["spatial_masks"] = e["spatial_masks"].double()
+    with pytest.raises(ValueError, match="spatial_masks"):
+        m(dbl)
+    got = m(dict(e))                                        # the well-formed entry still runs
+    for k in OUT_KEYS:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), ref[k])
+
+
+def test_shape_errors_like_the_reference(weights):
+    from nl_vsgg_amd.lib.sttran import STTran
+    e = _cuda_entry(syn.make_entry(342, [2, 2]))
+    m = _model(weights)
+    bad = dict(e); bad["spatial_masks"] = e["spatial_masks"][:, :, :26, :26].contiguous()
+    with pytest.raises(ValueError):
+        m(bad)
+    bad = dict(e); bad["union_feat"] = e["union_feat"][:, :1024].contiguous()
+    with pytest.raises(ValueError):
+        m(bad)
+    # sgdet: an entry that already went through forward carries the [B, 37] logits in `distribution`
+    sg = STTran(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES,
+                enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to("cuda:0")
+    sg.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()}, strict=False)
+    es = _cuda_entry(syn.make_entry(343, [2, 3], mode="sgdet", im_idx_dtype=np.int64))
+    out = sg(es)
+    assert out["distribution"].shape[1] == 37
+    with pytest.raises(ValueError, match="already forwarded"):
+        sg(out)
+
+
+def test_out_of_range_index_is_an_index_error(weights):
+    """check_indices defaults to True: the torch indexing of lib/sttran.py:381-393 raises IndexError"""
+    e = _cuda_entry(syn.make_entry(344, [2, 2]))
+    m = _model(weights)
+    assert m.check_indices is True
+    bad = dict(e); bad["pair_idx"] = e["pair_idx"].clone(); bad["pair_idx"][1, 1] = 10_000
+    with pytest.raises(IndexError):
+        m(bad)
+    m.check_indices = False
+    m(dict(bad))                                            # clamped, flagged on the device ...
+    with pytest.raises(IndexError):
+        m.sync_check()                                      # ... and reported when asked
+    m.sync_check()                                          # the flag is cleared by the report
