@@ -199,6 +199,20 @@ int32_t sttran_eval_max_pairs(int32_t num_predicates);
 int sttran_profile_enable(SttranHandle* h, int32_t enable);
 int sttran_profile_reset(SttranHandle* h);
 int sttran_profile_read(SttranHandle* h, SttranProfile* out); /* synchronises the stream */
+/* The same measurements broken down by (kernel template, problem shape): one entry per distinct launch site shape
+ * since profile_reset, so that a per-kernel roofline can be recomputed from the bench line alone.  `ms` includes the
+ * stream-K fix-up launch that belongs to a GEMM.  Call after sttran_profile_read (which folds the pending events in).
+ * Writes min(count, cap) entries and the total count. */
+typedef struct SttranProfEntry {
+  char kernel[96];      /* e.g. "gemm_sk_kernel<GemmTile<256,128,4,2,B_KMAJOR_PAD>,EpiLinear>"  */
+  int32_t cls;          /* STTRAN_PROF_*                                                         */
+  int32_t reserved;
+  int64_t M, N, K;      /* GEMM-shaped launches: C[M,N] += A[M,K] B[N,K]^T; otherwise rows / dim / 0 */
+  uint64_t launches;
+  double ms;            /* summed duration (HIP events on the forward's stream)                  */
+  double flops;         /* summed algorithmic FLOPs                                              */
+} SttranProfEntry;
+int sttran_profile_entries(SttranHandle* h, SttranProfEntry* out, int32_t cap, int32_t* count);
 
 /* Kernel-level test hooks: each runs ONE kernel class on caller-provided device buffers so the
  * parity tests can check kernels in isolation (tests/test_kernels_gpu.py). */

@@ -54,6 +54,12 @@ class SttranProfile(C.Structure):
                 ("bytes", C.c_double * PROF_CLASSES), ("launches", C.c_uint64 * PROF_CLASSES)]
 
 
+class SttranProfEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 96), ("cls", C.c_int32), ("reserved", C.c_int32),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("launches", C.c_uint64),
+                ("ms", C.c_double), ("flops", C.c_double)]
+
+
 class SttranEvalInputs(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("num_frames", C.c_int32), ("num_pairs", C.c_int32),
                 ("num_boxes", C.c_int32), ("num_gt_rels", C.c_int32),
@@ -82,6 +88,7 @@ SYMBOLS = [
     ("sttran_profile_enable", C.c_int, [C.c_void_p, C.c_int32]),
     ("sttran_profile_reset", C.c_int, [C.c_void_p]),
     ("sttran_profile_read", C.c_int, [C.c_void_p, C.POINTER(SttranProfile)]),
+    ("sttran_profile_entries", C.c_int, [C.c_void_p, C.POINTER(SttranProfEntry), C.c_int32, C.POINTER(C.c_int32)]),
     ("sttran_union_boxes_masks", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     ("sttran_eval_recall", C.c_int, [C.POINTER(SttranEvalInputs), C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/sttran_hip.h"
@@ -48,7 +49,13 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct ProfEvent { hipEvent_t a, b; int cls; };
+struct ProfEvent { hipEvent_t a, b; int cls; int entry; };
+struct ProfKey {
+  std::string kernel; int cls; int64_t M, N, K;
+  bool operator<(const ProfKey& o) const {
+    return std::tie(cls, kernel, M, N, K) < std::tie(o.cls, o.kernel, o.M, o.N, o.K);
+  }
+};
 
 // worst case of build_layout(): 2P (encoder off/len) + 6P (window off/len/q_begin) + 2P (dec_src) +
 // P (out_src) + P (need_idx) + 2P (tok0/tok1) + P/2 (slots) int32 words
@@ -92,6 +99,8 @@ struct SttranHandle {
   // profiling
   bool prof_on = false;
   std::vector<ProfEvent> prof_ev;
+  std::map<ProfKey, int> prof_index;            // (kernel, shape) -> entry
+  std::vector<SttranProfEntry> prof_entries;
   SttranProfile prof{};
   hipStream_t prof_stream = nullptr;
   int32_t* im_host = nullptr;   // pinned scratch for the im_idx read-back
@@ -195,12 +204,35 @@ void declare_weights(SttranHandle* h) {
 
 const float* W(SttranHandle* h, const std::string& k) { return h->w[k].d; }
 
+const char* tile_name(int tile) {
+  switch (tile) {
+    case TILE_256x128: return "256,128,4,2";
+    case TILE_128x128: return "128,128,2,2";
+    case TILE_128x64: return "128,64,2,2";
+    case TILE_64x64: return "64,64,2,2";
+    default: return "?";
+  }
+}
+
 struct ProfScope {
   SttranHandle* h; hipStream_t s; bool on;
   ProfEvent ev{};
-  ProfScope(SttranHandle* h_, hipStream_t s_, int cls, double flops, double bytes) : h(h_), s(s_), on(h_->prof_on) {
+  ProfScope(SttranHandle* h_, hipStream_t s_, int cls, double flops, double bytes, const std::string& kernel = std::string(),
+            int64_t M = 0, int64_t N = 0, int64_t K = 0) : h(h_), s(s_), on(h_->prof_on) {
     if (!on) return;
     ev.cls = cls;
+    ProfKey key{kernel, cls, M, N, K};
+    auto it = h->prof_index.find(key);
+    if (it == h->prof_index.end()) {
+      SttranProfEntry e{};
+      snprintf(e.kernel, sizeof(e.kernel), "%s", kernel.c_str());
+      e.cls = cls; e.M = M; e.N = N; e.K = K;
+      h->prof_entries.push_back(e);
+      it = h->prof_index.emplace(key, (int)h->prof_entries.size() - 1).first;
+    }
+    ev.entry = it->second;
+    h->prof_entries[ev.entry].launches += 1;
+    h->prof_entries[ev.entry].flops += flops;
     hipEventCreate(&ev.a);
     hipEventCreate(&ev.b);
     hipEventRecord(ev.a, s);
@@ -228,7 +260,8 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
-  ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K));
+  ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
+               std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
   HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>(), 1));
   return STTRAN_OK;
 }
@@ -253,14 +286,14 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
   if ((rc = run_linear(h, s, GemmOperand{xin, LD, nullptr}, W(h, p + ".self_attn.in_proj_weight"), M, 3 * D, D,
                        epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
   {
-    ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * M * maxlen * D, 4.0 * M * 4 * D);
+    ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * M * maxlen * D, 4.0 * M * 4 * D, "attention", M, maxlen, D);
     HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, LD, D, c.nhead));
   }
   EpiLinear eo = epi_plain(Y, LD, W(h, p + ".self_attn.out_proj.bias"));
   eo.res = xin; eo.ldres = LD;
   if ((rc = run_linear(h, s, GemmOperand{ATT, LD, nullptr}, W(h, p + ".self_attn.out_proj.weight"), M, D, D, eo))) return rc;
   {
-    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
+    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D, "layernorm_kernel", M, D, 0);
     HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, LD, M, D));
   }
   if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
@@ -269,7 +302,7 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
   e2.res = H; e2.ldres = LD;
   if ((rc = run_linear(h, s, GemmOperand{F1, LF, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2))) return rc;
   {
-    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D);
+    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D, "layernorm_kernel", M, D, 0);
     HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, LD, M, D));
   }
   return STTRAN_OK;
@@ -635,6 +668,8 @@ int sttran_profile_reset(SttranHandle* h) {
   if (!h) return STTRAN_ERR_INVALID;
   for (auto& e : h->prof_ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   h->prof_ev.clear();
+  h->prof_index.clear();
+  h->prof_entries.clear();
   memset(&h->prof, 0, sizeof(h->prof));
   return STTRAN_OK;
 }
@@ -646,12 +681,20 @@ int sttran_profile_read(SttranHandle* h, SttranProfile* out) {
     float ms = 0.f;
     HIPCK(hipEventElapsedTime(&ms, e.a, e.b));
     h->prof.ms[e.cls] += ms;
+    if (e.entry >= 0 && e.entry < (int)h->prof_entries.size()) h->prof_entries[e.entry].ms += ms;
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
   }
   h->prof_ev.clear();
   h->prof.struct_size = sizeof(SttranProfile);
   *out = h->prof;
+  return STTRAN_OK;
+}
+
+int sttran_profile_entries(SttranHandle* h, SttranProfEntry* out, int32_t cap, int32_t* count) {
+  if (!h || !count || cap < 0 || (cap > 0 && !out)) return STTRAN_ERR_INVALID;
+  *count = (int32_t)h->prof_entries.size();
+  for (int32_t i = 0; i < cap && i < *count; ++i) out[i] = h->prof_entries[i];
   return STTRAN_OK;
 }
 
@@ -779,7 +822,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     const int zd = FD + 200 + 128;
     const int64_t ldz = pad32(zd);
     {
-      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * B * (2.0 * zd));
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * B * (2.0 * zd), "objcls_prep_kernel", B, zd, 0);
       HIPCK(launch_objcls_prep(s, in->features, in->distribution, in->boxes, W(h, "object_classifier.obj_embed.weight"),
                                h->oc_pos_scale, h->oc_pos_shift, W(h, "object_classifier.pos_embed.1.weight"),
                                W(h, "object_classifier.pos_embed.1.bias"), Z, ldz, (int)B, FD, NC - 1, 200));
@@ -793,7 +836,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
 
   // ---- pair fusion (lib/sttran.py:381-399) -> X0 [P, 1936] -----------------------------------
   {
-    ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2);
+    ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2, "pair_prep_kernel", P, 400, 0);
     HIPCK(launch_pair_prep(s, in->pair_idx, in->labels, (int)P, (int)B, NC, W(h, "obj_embed.weight"),
                            W(h, "obj_embed2.weight"), 200, subj_idx, obj_idx, X0, (int)LD, 1536, h->err_flag));
   }
@@ -805,16 +848,19 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
     {
       // conv 7x7/2 -> ReLU -> BN -> max-pool in one kernel; the [P,128,14,14] intermediate stays on chip
-      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 49));
+      ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 49), "mask_conv1_pool_kernel",
+                   128, P * 196, 98);
       HIPCK(launch_mask_conv1_pool(s, in->spatial_masks, h->w0_perm, W(h, "conv.0.bias"), h->bn1_scale,
                                    h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
-    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152));
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
+                 "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
     HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
   }
   {
-    ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD);
+    ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
+                 "gemm_sk_kernel<GemmTile<128,256,2,4,B_UNION>,EpiUnion>", 256, P * 49, FD);
     HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                             h->slab.as<float>()));
   }
@@ -847,7 +893,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     //      whole clip, sinusoidal PE by the pair's frame rank inside its sequence, 3 encoder layers.
     //      dec_src = pair of each sequence token, need = its PE row, dec_off/len = class sequences.
     {
-      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 12.0 * P * D);
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 12.0 * P * D, "gather_add_rows_kernel", P, D, 0);
       HIPCK(launch_gather_add_rows(s, UNI, LD, dec_src, W(h, "positional_encoder.pe"), D, need, G, LD, P, D));
     }
     const float* gin = G;
@@ -861,7 +907,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
   if (NT > 0 && c.dec_layers > 0) {
     {
-      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D);
+      ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D, "gather_rows_kernel", NT, D, 0);
       HIPCK(launch_gather_rows(s, UNI, LD, dec_src, G, LD, NT, D));
     }
     for (int i = 0; i < c.dec_layers; ++i) {
@@ -896,7 +942,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
         if ((rc = run_linear(h, s, GemmOperand{G, LD, need}, Win, NN, D, D, eq))) return rc;
       }
       {
-        ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * MQ * L.max_dec * D, 4.0 * (MQ * 2.0 + NT * 2.0) * D);
+        ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * MQ * L.max_dec * D, 4.0 * (MQ * 2.0 + NT * 2.0) * D, "attention", MQ,
+                     L.max_dec, D);
         HIPCK(launch_attention(s, QKV, dec_off, dec_len, last ? qbegin : nullptr, L.n_dec_seq, L.max_dec, ATT, LD, D,
                                c.nhead));
       }
@@ -904,7 +951,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       eo.res = G; eo.ldres = LD; eo.res_rowidx = rows;
       if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
       {
-        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D);
+        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D, "layernorm_kernel", MQ, D, 0);
         HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, LD, MQ, D));
       }
       if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), MQ, F, D,
@@ -926,7 +973,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     EpiHeads eh{out->attention_distribution, out->spatial_distribution, out->contacting_distribution, h->heads_b,
                 c.attention_classes, c.spatial_classes, c.contact_classes};
     GemmPlan plan = plan_gemm(P, nh, D, TILE_64x64, 1);
-    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D));
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D),
+                 "gemm_sk_kernel<GemmTile<64,64,2,2,B_KMAJOR_PAD>,EpiHeads>", P, nh, D);
     HIPCK(gemm_heads(s, GemmOperand{UNI, LD, out_src}, GemmOperand{h->heads_w, pad32(D), nullptr}, (int)P, nh, D, eh, plan,
                      h->slab.as<float>()));
   }

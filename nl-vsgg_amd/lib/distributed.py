@@ -6,6 +6,13 @@ the MI355X design is: one process per GPU, a full weight replica each, clips ass
 no collective on the data path, and ONE fixed-stride all-gather per batch of clips that brings
 every rank's `[pairs, 26]` prediction rows to all ranks (rank 0 then runs the evaluator).
 `torch.distributed`'s "nccl" backend is RCCL on ROCm; the same code runs on "gloo" for CPU tests.
+
+Two entry points over the same code:
+  * `PredictionGatherer` -- the pipelined form `bench.py --gpus N` times: fixed capacities, a ring of
+    buffers, gathers issued asynchronously (RCCL's stream, under the next forward), **no host
+    synchronisation** until a result is asked for;
+  * `all_gather_predictions` -- one-shot convenience (returns the per-clip dict); without capacities it
+    first exchanges sizes, which costs two host synchronisations.
 """
 from __future__ import annotations
 
@@ -28,48 +35,131 @@ def assign_clips(costs, world_size):
     return owner
 
 
-def pack_predictions(pred):
-    """[P, 3 + 6 + 17] rows: attention logits | spatial | contacting probabilities."""
-    return torch.cat([pred["attention_distribution"], pred["spatial_distribution"],
-                      pred["contacting_distribution"]], dim=1)
+def pack_predictions(pred, out=None):
+    """[P, 3 + 6 + 17] rows: attention logits | spatial | contacting probabilities (into `out[:P]` if given)."""
+    parts = [pred["attention_distribution"], pred["spatial_distribution"], pred["contacting_distribution"]]
+    if out is None:
+        return torch.cat(parts, dim=1)
+    P = parts[0].shape[0]
+    torch.cat(parts, dim=1, out=out[:P])
+    return out[:P]
 
 
-def all_gather_predictions(local_rows, local_clip_ids, local_clip_pairs, group=None, rows_cap=None):
-    """Gather per-clip prediction rows from every rank.
+class PredictionGatherer:
+    """Fixed-capacity, pipelined all-gather of per-clip prediction rows.
 
-    local_rows      [sum(local_clip_pairs), C] tensor on this rank's device
-    local_clip_ids  global ids of this rank's clips, in row order
+    Every rank contributes one `[rows_cap, cols]` payload and one `[clips_cap, 2]` int64 record of
+    (global clip id, rows of that clip) per `submit`; unused slots carry id -1.  `depth` buffer sets form
+    a ring: `submit` first makes the current stream wait for the gather that used the same set `depth`
+    submits ago, copies the rows in and issues both all-gathers with `async_op=True` -- on RCCL that
+    only enqueues (the collectives run on RCCL's stream, ordered after the copy by the work handle);
+    nothing on this path reads a device value back.  `result(ticket)` is the one synchronising call.
+    The clip records are uploaded once per distinct (ids, rows) layout and cached on the device."""
+
+    def __init__(self, rows_cap, clips_cap, cols=26, device=None, group=None, depth=2, dtype=torch.float32):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rows_cap, self.clips_cap, self.cols, self.depth = int(rows_cap), int(clips_cap), int(cols), int(depth)
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        self.device = dev
+        self._payload = [torch.zeros((self.rows_cap, cols), device=dev, dtype=dtype) for _ in range(depth)]
+        self._gathered = [torch.empty((self.world * self.rows_cap, cols), device=dev, dtype=dtype) for _ in range(depth)]
+        self._meta_all = [torch.empty((self.world * self.clips_cap, 2), device=dev, dtype=torch.int64) for _ in range(depth)]
+        self._works = [None] * depth
+        self._meta_cache = {}
+        self._n = 0
+
+    def _meta(self, clip_ids, clip_pairs):
+        key = (tuple(int(i) for i in clip_ids), tuple(int(p) for p in clip_pairs))
+        m = self._meta_cache.get(key)
+        if m is None:
+            if len(key[0]) != len(key[1]) or len(key[0]) > self.clips_cap:
+                raise ValueError(f"{len(key[0])} clips / {len(key[1])} row counts exceed clips_cap={self.clips_cap}")
+            if sum(key[1]) > self.rows_cap:
+                raise ValueError(f"{sum(key[1])} prediction rows exceed rows_cap={self.rows_cap}")
+            host = torch.full((self.clips_cap, 2), -1, dtype=torch.int64)
+            if key[0]:
+                host[: len(key[0]), 0] = torch.tensor(key[0], dtype=torch.int64)
+                host[: len(key[0]), 1] = torch.tensor(key[1], dtype=torch.int64)
+            m = host.to(self.device)
+            if len(self._meta_cache) > 64:
+                self._meta_cache.clear()
+            self._meta_cache[key] = m
+        return m
+
+    def payload(self):
+        """The `[rows_cap, cols]` buffer the NEXT submit will send: a producer may write its rows straight into it
+        (`pack_predictions(pred, out=g.payload())`) and pass the returned view to `submit` -- no extra copy."""
+        k = self._n % self.depth
+        self._wait(k)
+        return self._payload[k]
+
+    def _wait(self, k):
+        if self._works[k] is not None:
+            for w in self._works[k]:
+                w.wait()
+            self._works[k] = None
+
+    def submit(self, local_rows, clip_ids, clip_pairs):
+        """Issue the gather of this rank's rows (`[sum(clip_pairs), cols]`); returns a ticket for `result`."""
+        k = self._n % self.depth
+        self._wait(k)
+        n = int(local_rows.shape[0])
+        meta = self._meta(clip_ids, clip_pairs)
+        if n != sum(int(p) for p in clip_pairs):
+            raise ValueError("local_rows does not have sum(clip_pairs) rows")
+        buf = self._payload[k]
+        if n and local_rows.data_ptr() != buf.data_ptr():
+            buf[:n].copy_(local_rows)
+        w1 = dist.all_gather_into_tensor(self._meta_all[k], meta, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(self._gathered[k], buf, group=self.group, async_op=True)
+        self._works[k] = (w1, w2)
+        ticket = self._n
+        self._n += 1
+        return ticket
+
+    def wait_all(self):
+        """Make the current stream (gloo: the host) wait for every gather still in flight."""
+        for k in range(self.depth):
+            self._wait(k)
+
+    def result(self, ticket):
+        """{clip_id: [pairs, cols] tensor} of the gather `ticket` (views into its buffer set: valid until that set
+        is reused, i.e. for the next `depth - 1` submits).  Synchronises: reads the clip records back."""
+        if not (self._n - self.depth <= ticket < self._n):
+            raise ValueError("that gather's buffers have been reused")
+        k = ticket % self.depth
+        self._wait(k)
+        meta = self._meta_all[k].view(self.world, self.clips_cap, 2).cpu()
+        out = {}
+        for r in range(self.world):
+            off = r * self.rows_cap
+            for cid, rows in meta[r].tolist():
+                if cid < 0:
+                    continue
+                out[int(cid)] = self._gathered[k][off: off + rows]
+                off += rows
+        return out
+
+
+def all_gather_predictions(local_rows, local_clip_ids, local_clip_pairs, group=None, rows_cap=None, clips_cap=None):
+    """Gather per-clip prediction rows from every rank (one-shot form of `PredictionGatherer`).
+
+    local_rows       [sum(local_clip_pairs), C] tensor on this rank's device
+    local_clip_ids   global ids of this rank's clips, in row order
     local_clip_pairs rows per clip
-    rows_cap        optional known upper bound of rows per rank (skips the size exchange; the bench
-                    uses it because every rank runs identical shapes)
+    rows_cap, clips_cap  known upper bounds per rank of rows / clips.  With BOTH given nothing is exchanged
+                     beforehand and the only host synchronisation is the final read of the clip records; if either
+                     is missing the ranks first agree on it (one all-reduce + `.item()` each).
     Returns {clip_id: [pairs, C] tensor} for all clips of all ranks (views into one gathered buffer).
-    One small all-gather of (id, rows) metadata + one all-gather of a fixed-stride payload; the
-    payload is sub-MB per clip, i.e. latency-bound, so it is sent once per batch, not per clip."""
-    world = dist.get_world_size(group)
-    dev, C = local_rows.device, local_rows.shape[1]
-    n_local = len(local_clip_ids)
-    n_max = torch.tensor([n_local], device=dev, dtype=torch.int64)
-    dist.all_reduce(n_max, op=dist.ReduceOp.MAX, group=group)
-    n_max = int(n_max.item())
-    meta = torch.full((n_max, 2), -1, device=dev, dtype=torch.int64)
-    if n_local:
-        meta[:n_local, 0] = torch.as_tensor(local_clip_ids, device=dev, dtype=torch.int64)
-        meta[:n_local, 1] = torch.as_tensor(local_clip_pairs, device=dev, dtype=torch.int64)
-    all_meta = torch.empty((world, n_max, 2), device=dev, dtype=torch.int64)
-    dist.all_gather_into_tensor(all_meta.view(world * n_max, 2), meta, group=group)
-    all_meta = all_meta.cpu()
-    if rows_cap is None:
-        rows_cap = int(all_meta[:, :, 1].clamp(min=0).sum(dim=1).max().item())
-    payload = torch.zeros((rows_cap, C), device=dev, dtype=local_rows.dtype)
-    payload[: local_rows.shape[0]] = local_rows
-    gathered = torch.empty((world * rows_cap, C), device=dev, dtype=local_rows.dtype)
-    dist.all_gather_into_tensor(gathered, payload, group=group)
-    out = {}
-    for r in range(world):
-        off = r * rows_cap
-        for cid, rows in all_meta[r].tolist():
-            if cid < 0:
-                continue
-            out[int(cid)] = gathered[off: off + rows]
-            off += rows
-    return out
+    The payload is sub-MB per clip, i.e. latency-bound, so it is sent once per batch, not per clip."""
+    dev = local_rows.device
+    if rows_cap is None or clips_cap is None:
+        need = torch.tensor([len(local_clip_ids), int(local_rows.shape[0])], device=dev, dtype=torch.int64)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+        n_clips, n_rows = (int(v) for v in need.tolist())
+        clips_cap = max(n_clips, 1) if clips_cap is None else clips_cap
+        rows_cap = max(n_rows, 1) if rows_cap is None else rows_cap
+    g = PredictionGatherer(rows_cap, clips_cap, cols=local_rows.shape[1], device=dev, group=group, depth=1,
+                           dtype=local_rows.dtype)
+    return g.result(g.submit(local_rows, local_clip_ids, local_clip_pairs))

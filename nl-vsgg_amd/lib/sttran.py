@@ -185,6 +185,16 @@ class STTran:
         return {nat.PROF_NAMES[i]: {"ms": p.ms[i], "flops": p.flops[i], "bytes": p.bytes[i],
                                     "launches": int(p.launches[i])} for i in range(7)} | {"forwards": int(p.forwards)}
 
+    def profile_entries(self):
+        """Per (kernel template, shape) breakdown of the same measurements (call after `profile_read`)."""
+        n = C.c_int32(0)
+        nat.check(self._lib, self._handle, self._lib.sttran_profile_entries(self._handle, None, 0, C.byref(n)))
+        arr = (nat.SttranProfEntry * max(n.value, 1))()
+        nat.check(self._lib, self._handle, self._lib.sttran_profile_entries(self._handle, arr, n.value, C.byref(n)))
+        return [{"kernel": arr[i].kernel.decode(), "class": nat.PROF_NAMES[arr[i].cls], "M": arr[i].M, "N": arr[i].N,
+                 "K": arr[i].K, "launches": int(arr[i].launches), "ms": arr[i].ms, "flops": arr[i].flops}
+                for i in range(n.value)]
+
     def reserve(self, max_pairs, max_boxes):
         self._ensure_handle()
         nat.check(self._lib, self._handle, self._lib.sttran_reserve(self._handle, int(max_pairs), int(max_boxes)))

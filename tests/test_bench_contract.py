@@ -32,4 +32,5 @@ def test_bench_accepts_the_driver_flags():
     for flag in ("--gpus", "--steps", "--warmup"):
         assert re.search(rf'add_argument\("{flag}"', src), flag
     assert 'dist.all_reduce(t, op=dist.ReduceOp.MAX)' in src          # max over ranks
-    assert src.count("barrier()") >= 3                                  # both sides of the timed region
+    assert src.count("env.barrier(gatherer)") >= 2                      # both sides of the timed region
+    assert "PredictionGatherer" in src                                  # the tested gather is the timed gather

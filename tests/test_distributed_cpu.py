@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from nl_vsgg_amd.lib.distributed import all_gather_predictions, assign_clips
+from nl_vsgg_amd.lib.distributed import PredictionGatherer, all_gather_predictions, assign_clips, pack_predictions
 
 
 def _free_port():
@@ -51,6 +51,91 @@ def test_all_gather_predictions_world2(pairs):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2]                 # both ranks derived the same clip -> rank map
+
+
+def _rows(i, n, step=0):
+    return torch.full((n, 26), float(i) + 100.0 * step) + torch.arange(n).float()[:, None] * 1e-3
+
+
+def _worker_pipelined(rank, world, port, pairs, steps, q):
+    """the form bench.py --gpus N runs: fixed capacities, a ring of two buffer sets, one submit per step, results
+    read only afterwards (and while later gathers are already in flight)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        owner = assign_clips(pairs, world)
+        mine = [i for i, o in enumerate(owner) if o == rank]
+        rows_cap = max(sum(pairs[i] for i, o in enumerate(owner) if o == r) for r in range(world))
+        clips_cap = max(sum(1 for o in owner if o == r) for r in range(world))
+        g = PredictionGatherer(rows_cap, clips_cap, cols=26, depth=2)
+        ok = True
+        tickets = []
+        for step in range(steps):
+            buf = g.payload()                                  # write the rows straight into the send buffer
+            n = sum(pairs[i] for i in mine)
+            if n:
+                buf[:n] = torch.cat([_rows(i, pairs[i], step) for i in mine])
+            tickets.append(g.submit(buf[:n], mine, [pairs[i] for i in mine]))
+            if step >= 1:                                      # read the previous step while this one is in flight
+                got = g.result(tickets[step - 1])
+                ok = ok and sorted(got) == list(range(len(pairs)))
+                for i, t in got.items():
+                    ok = ok and torch.equal(t, _rows(i, pairs[i], step - 1))
+        g.wait_all()
+        got = g.result(tickets[-1])
+        for i, t in got.items():
+            ok = ok and torch.equal(t, _rows(i, pairs[i], steps - 1))
+        try:
+            g.result(tickets[0])                               # its buffers were reused long ago
+            ok = False
+        except ValueError:
+            pass
+        # the one-shot form with both capacities given (no size exchange)
+        local = torch.cat([_rows(i, pairs[i]) for i in mine]) if mine else torch.zeros((0, 26))
+        got = all_gather_predictions(local, mine, [pairs[i] for i in mine], rows_cap=rows_cap, clips_cap=clips_cap)
+        ok = ok and all(torch.equal(got[i], _rows(i, pairs[i])) for i in range(len(pairs)))
+        # pack_predictions into the send buffer
+        pred = {"attention_distribution": torch.rand(3, 3), "spatial_distribution": torch.rand(3, 6),
+                "contacting_distribution": torch.rand(3, 17)}
+        view = pack_predictions(pred, out=torch.zeros(5, 26))
+        ok = ok and torch.equal(view, pack_predictions(pred)) and view.shape == (3, 26)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pairs", [[5, 1, 7, 3, 3], [4], [2, 2, 2, 2, 6, 1]])
+def test_pipelined_gatherer_world2(pairs):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, pairs, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_gatherer_rejects_overflow():
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = PredictionGatherer(rows_cap=4, clips_cap=2, cols=26)
+        with pytest.raises(ValueError):
+            g.submit(torch.zeros(5, 26), [0], [5])
+        with pytest.raises(ValueError):
+            g.submit(torch.zeros(3, 26), [0, 1, 2], [1, 1, 1])
+        with pytest.raises(ValueError):
+            g.submit(torch.zeros(3, 26), [0], [2])
+        got = g.result(g.submit(torch.ones(3, 26), [7], [3]))
+        assert list(got) == [7] and torch.equal(got[7], torch.ones(3, 26))
+    finally:
+        dist.destroy_process_group()
 
 
 def test_assign_clips_balances_and_is_deterministic():
