@@ -82,18 +82,20 @@ def test_ag_split_shaped_loop(golden_dir):
     ev_dev.calculate_mean_recall(); ev_host.calculate_mean_recall()
     torch.cuda.synchronize()
 
-    # (1) identical evaluation: every recall list of every metric, and the mean-recall tables
-    n_lists = 0
-    for key, table in ev_host.result_dict.items():
-        assert key in ev_dev.result_dict, key
-        for k, v in table.items():
-            got = ev_dev.result_dict[key][k]
-            if isinstance(v, dict):
-                assert {kk: list(map(float, vv)) for kk, vv in v.items()} == {kk: list(map(float, vv)) for kk, vv in got.items()}, (key, k)
-            else:
-                assert list(map(float, np.ravel(v))) == list(map(float, np.ravel(got))), (key, k)
-            n_lists += 1
-    assert n_lists >= 9
+    # (1) identical evaluation: every recall list of every metric, the per-predicate collections and the mean-recall tables
+    def same(x, y, path):
+        if isinstance(x, dict):
+            assert isinstance(y, dict) and set(x) == set(y), path
+            for k in x:
+                same(x[k], y[k], path + (k,))
+        elif isinstance(x, (list, tuple)):
+            assert len(x) == len(y), path
+            for i, (u, v) in enumerate(zip(x, y)):
+                same(u, v, path + (i,))
+        else:
+            assert float(x) == float(y), path
+    assert set(ev_host.result_dict) == set(ev_dev.result_dict)
+    same(ev_host.result_dict, ev_dev.result_dict, ())
     assert len(ev_host.result_dict["predcls_recall"][20]) == sum(c[0]["num_frames"] for c in clips)
 
     # (2) sampled clips vs the fp64 oracle, (3) packed == single
