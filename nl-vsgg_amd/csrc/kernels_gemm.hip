@@ -21,7 +21,10 @@ struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
     {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
-    {128, 256, 0.80f, 1}};   // last: TILE_UNION (never chosen by plan_gemm)
+    {128, 256, 0.80f, 1},    // TILE_UNION (never chosen by plan_gemm)
+    // gemm_dma.h tiles: LDS = 64 / 96 / 48 / 32 KB per workgroup
+    {128, 128, 0.92f, 2}, {256, 128, 0.92f, 1}, {128, 64, 0.88f, 3}, {64, 64, 0.80f, 4}};
+static bool is_dma_tile(int t) { return t >= TILE_D128x128 && t <= TILE_D64x64; }
 
 int num_cus() {
   static int cus[kMaxDevices] = {};
@@ -54,8 +57,14 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   GemmPlan best{TILE_128x128, 1};
   double best_t = 1e300;
   const int64_t ksteps = (K + kBK - 1) / kBK;
-  for (int t = 1; t < TILE_UNION; ++t) {
+  static const int env_tile = getenv("STTRAN_GEMM_TILE") ? atoi(getenv("STTRAN_GEMM_TILE")) : 0;   // experiments only
+  static const int env_gen = getenv("STTRAN_GEMM_GEN") ? atoi(getenv("STTRAN_GEMM_GEN")) : 0;      // 1 = old tiles only, 2 = DMA tiles only
+  if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT && env_tile != TILE_UNION) force_tile = env_tile;
+  for (int t = 1; t < TILE_COUNT; ++t) {
+    if (t == TILE_UNION) continue;
     if (force_tile && t != force_tile) continue;
+    if (!force_tile && env_gen == 1 && is_dma_tile(t)) continue;
+    if (!force_tile && env_gen == 2 && !is_dma_tile(t)) continue;
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -134,6 +143,58 @@ static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, 
 #endif
 }
 
+// ---- gemm_dma.h launch ----------------------------------------------------------------------------------------
+template <class T, class Epi>
+static hipError_t launch_dma_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
+                                  int K, float* slab, const Epi& epi) {
+  static DeviceMarks marks;
+  auto kern = gemm_dma_kernel<T, Epi>;
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
+  const int ksteps = (K + kBK - 1) / kBK;
+  const SkPlan sp = sk_plan(tile_id, tiles, ksteps);
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
+  bool split = false;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  // workgroups dispatched after the first one-per-CU wave walk their work in the opposite order (gemm_dma.h)
+  const int half = sp.G > num_cus() ? std::max(num_cus(), sp.G / 2) : sp.G;
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
+                     sp.g_sk, base, rem, half, slab, epi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !split) return e;
+  hipLaunchKernelGGL((gemm_dma_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
+                     ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
+  return hipGetLastError();
+}
+
+template <class Epi>
+static hipError_t gemm_dma_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                                   const Epi& epi, GemmPlan plan, float* slab) {
+  // LDS-DMA fetches 16-byte chunks: operand rows must be 16-byte aligned
+  if ((reinterpret_cast<uintptr_t>(A.ptr) & 15) || (reinterpret_cast<uintptr_t>(B.ptr) & 15) || (A.ld & 3) || (B.ld & 3))
+    return hipErrorInvalidValue;
+  switch (plan.tile) {
+    case TILE_D128x128: return launch_dma_tile<DmaTile<128, 128, 2, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_D256x128: return launch_dma_tile<DmaTile<256, 128, 4, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    case TILE_D128x64: return launch_dma_tile<DmaTile<128, 64, 2, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
+    default: return launch_dma_tile<DmaTile<64, 64, 2, 2>, Epi>(s, TILE_D64x64, A, B, M, N, K, slab, epi);
+  }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// can EpiLinear run as 16-byte vectors?  (every pointer it dereferences at a column that is a multiple of 4)
+static bool epi_vectorizable(const EpiLinear& e, int N) {
+  return (N & 3) == 0 && aligned16(e.C) && (e.ldc & 3) == 0 && aligned16(e.bias) && aligned16(e.rowbias) &&
+         (e.rb_ld & 3) == 0 && (e.rb_cols & 3) == 0 && aligned16(e.scale) && aligned16(e.shift) && aligned16(e.res) &&
+         (e.ldres & 3) == 0;
+}
+
 template <class Epi, int BK>
 static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                                const Epi& epi, GemmPlan plan, float* slab) {
@@ -150,11 +211,20 @@ static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOp
 // only as far as the caller's ld says -- what matters is that ceil32(K) columns of every row are readable.
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                        const EpiLinear& epi, GemmPlan plan, float* slab, int padded) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (is_dma_tile(plan.tile)) {
+    if (!padded) return hipErrorInvalidValue;
+    if (epi_vectorizable(epi, N)) return gemm_dma_generic<EpiLinearV>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
+    return gemm_dma_generic<EpiScalar4<EpiLinear>>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
+  }
   return padded ? gemm_generic<EpiLinear, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab)
                 : gemm_generic<EpiLinear, B_KMAJOR>(s, A, B, M, N, K, epi, plan, slab);
 }
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (is_dma_tile(plan.tile))
+    return gemm_dma_generic<EpiScalar4<EpiHeads>>(s, A, B, M, N, K, EpiScalar4<EpiHeads>{epi}, plan, slab);
   return gemm_generic<EpiHeads, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab);     // product only: padded operands
 }
 // union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nl_vsgg_amd import _native  # noqa: E402
 
-TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64"}
+TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64", 6: "D128x128", 7: "D256x128", 8: "D128x64", 9: "D64x64"}
 
 
 def path_shapes(P, NT):
@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--tiles", default="1,2,3,4")
     ap.add_argument("--pipes", default="0", help="main-loop variants (library built with EXTRA=-DSTTRAN_GEMM_EXPERIMENT)")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--residual", action="store_true", help="add a residual [M,N] in the epilogue (out-proj / FFN2 form)")
     ap.add_argument("--zeros", action="store_true", help="zero operands: separates clock (power) limits from schedule limits")
     ap.add_argument("--cold", action="store_true",
                     help="overwrite a 768 MB buffer before every timed launch (operands come from HBM, not from the "
@@ -60,13 +61,15 @@ def main():
             A.zero_(); W.zero_()
         b = torch.randn(N, device="cuda")
         Cc = torch.empty(M, N, device="cuda")
+        R = torch.randn(M, N, device="cuda") if a.residual else None
+        pr = p(R) if a.residual else None
         best = None
         rows = []
         for tile in [0] + [int(t) for t in a.tiles.split(",")]:
             for split in ([0] if tile == 0 else [int(s) for s in a.pipes.split(",")]):
                 os.environ["STTRAN_GEMM_PIPE"] = str(split)     # only read by EXPERIMENT builds
                 for _ in range(2):
-                    lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
+                    lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, tile, None)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 if a.cold:
@@ -74,14 +77,14 @@ def main():
                     for _ in range(a.iters):
                         flush.add_(1.0)
                         e0.record()
-                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
+                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, tile, None)
                         e1.record()
                         torch.cuda.synchronize()
                         us += e0.elapsed_time(e1) * 1e3 / a.iters
                 else:
                     e0.record()
                     for _ in range(a.iters):
-                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), None, p(Cc), M, N, K, 0, tile, None)
+                        lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, tile, None)
                     e1.record()
                     torch.cuda.synchronize()
                     us = e0.elapsed_time(e1) * 1e3 / a.iters
