@@ -40,44 +40,6 @@ struct DmaTile {
   static_assert(BM % 16 == 0, "the swizzle of a B row must not depend on BM");
 };
 
-// Vector epilogue of EpiLinear: four consecutive columns of one row (col % 4 == 0, col + 3 < N, every pointer
-// 16-byte aligned at such columns -- the launcher checks).
-struct EpiLinearV {
-  EpiLinear e;
-  __device__ __forceinline__ void put4(int orow, int row, int col, f32x4 v) const {
-    if (e.rowbias && col < e.rb_cols)
-      v += *reinterpret_cast<const f32x4*>(e.rowbias + (int)e.rowslot[orow] * e.rb_ld + col);
-    if (e.scale) v = v * *reinterpret_cast<const f32x4*>(e.scale + col) + *reinterpret_cast<const f32x4*>(e.shift + col);
-    if (e.relu) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = relu_nan(v[c]);
-    }
-    if (e.res) v += *reinterpret_cast<const f32x4*>(e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[row] : row) * e.ldres + col);
-    *reinterpret_cast<f32x4*>(e.C + (int64_t)orow * e.ldc + col) = v;
-  }
-  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
-    if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
-    if (!e.out_rowidx) { put4(row, row, col, v); return; }
-    const int o1 = e.out_rowidx[row];
-    if (o1 >= 0) put4(o1, row, col, v);
-    if (e.out_rowidx2) {
-      const int o2 = e.out_rowidx2[row];
-      if (o2 >= 0) put4(o2, row, col, v);
-    }
-  }
-  __device__ __forceinline__ void operator()(int row, int col, float v) const { e(row, col, v); }
-};
-// element-wise functors (heads, unaligned outputs) get a vec() that falls back to four scalar calls
-template <class Epi>
-struct EpiScalar4 {
-  Epi e;
-  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) e(row, col + c, v[c]);
-  }
-  __device__ __forceinline__ void operator()(int row, int col, float v) const { e(row, col, v); }
-};
-
 // ORDER: 0 = whole tiles first, then the stream-K range; 1 = the other way round for the second-dispatched half of
 // the grid (blockIdx.x >= half), see the file comment.
 template <class T, class Epi>

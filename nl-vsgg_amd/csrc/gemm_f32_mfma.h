@@ -140,6 +140,54 @@ struct EpiUnion {
   }
 };
 
+// Vector epilogue of EpiLinear: four consecutive columns of one row (col % 4 == 0, col + 3 < N, every pointer
+// 16-byte aligned at such columns -- the launcher checks).
+struct EpiLinearV {
+  static constexpr bool kVector = true;
+  EpiLinear e;
+  __device__ __forceinline__ void put4(int orow, int row, int col, f32x4 v) const {
+    if (e.rowbias && col < e.rb_cols)
+      v += *reinterpret_cast<const f32x4*>(e.rowbias + (int)e.rowslot[orow] * e.rb_ld + col);
+    if (e.scale) v = v * *reinterpret_cast<const f32x4*>(e.scale + col) + *reinterpret_cast<const f32x4*>(e.shift + col);
+    if (e.relu) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = relu_nan(v[c]);
+    }
+    if (e.res) v += *reinterpret_cast<const f32x4*>(e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[row] : row) * e.ldres + col);
+    *reinterpret_cast<f32x4*>(e.C + (int64_t)orow * e.ldc + col) = v;
+  }
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+    if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + col);
+    if (!e.out_rowidx) { put4(row, row, col, v); return; }
+    const int o1 = e.out_rowidx[row];
+    if (o1 >= 0) put4(o1, row, col, v);
+    if (e.out_rowidx2) {
+      const int o2 = e.out_rowidx2[row];
+      if (o2 >= 0) put4(o2, row, col, v);
+    }
+  }
+  __device__ __forceinline__ void operator()(int row, int col, float v) const { e(row, col, v); }
+};
+// element-wise functors (heads, unaligned outputs) get a vec() that falls back to four scalar calls
+template <class Epi>
+struct EpiScalar4 {
+  static constexpr bool kVector = true;
+  Epi e;
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e(row, col + c, v[c]);
+  }
+  __device__ __forceinline__ void operator()(int row, int col, float v) const { e(row, col, v); }
+};
+
+// An epilogue with a vec() member asks for the SWAPPED MFMA operand ports (weights on the "A" port, activations on the
+// "B" port): a lane's 16 accumulator registers then hold, for ONE output row (lane & 31), four groups of four
+// CONSECUTIVE columns (8 q + 4 (lane >> 5) + {0..3}), so bias / residual are loaded and C is stored as 16-byte vectors
+// -- a quarter of the memory instructions of the column-per-lane layout.  The k order inside an accumulator is the same
+// either way (the result is bit-identical).
+template <class Epi, class = void> struct EpiTraits { static constexpr bool swap = false; };
+template <class Epi> struct EpiTraits<Epi, decltype((void)Epi::kVector)> { static constexpr bool swap = Epi::kVector; };
+
 template <int BM_, int BN_, int WM_, int WN_, int BKIND_ = B_KMAJOR>
 struct GemmTile {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BKIND = BKIND_;
@@ -204,12 +252,13 @@ __host__ __device__ __forceinline__ int sk_owner(int it, int base, int rem) {
 template <class T, class Epi, int PIPE>
 __global__ void __launch_bounds__(T::NT)
 gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
-               int g_sk, int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
+               int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
   constexpr bool CONV = T::BKIND == B_CONV2;
   constexpr bool PADDED = T::BKIND == B_KMAJOR_PAD;
+  constexpr bool SWAP = EpiTraits<Epi>::swap;
   using Geo = ConvGeo<T::BKIND>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -237,11 +286,15 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
   const int blk = xcd_remap(blockIdx.x, G);      // neighbouring ranges (shared weight panels) on one XCD
   const int tiles_dp = dp_per_wg * G;
   const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
+  // Workgroups dispatched after the first one-per-CU wave (blockIdx.x >= half) walk their work in the opposite order
+  // -- stream-K range first, whole tiles after -- so that the workgroups sharing a CU reach their epilogues (no MFMAs)
+  // at different times and one keeps the matrix pipe busy while the other stores.  Speed only: any order is correct.
+  const bool sk_first = (int)blockIdx.x >= half;
 
   int dp_done = 0;
   for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
     int tile, ks0, ks1;
-    const bool dp = dp_done < dp_per_wg;
+    const bool dp = sk_first ? !(it < rg.end) : dp_done < dp_per_wg;
     if (dp) {
       tile = dp_done * G + blk;                   // at any moment the workgroups of an XCD hold consecutive tiles
       ks0 = 0; ks1 = ksteps;
@@ -385,14 +438,18 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // one MFMA; SWAP feeds the B fragment to the "A" port (see EpiTraits)
+    auto mfma1 = [&](f32x16& c, float a, float b) {
+      if constexpr (SWAP) c = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, c, 0, 0, 0);
+      else c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    };
     auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) mfma1(acc[i][j], fa[i][e], fb[j][e]);
     };
 
     // Operand kinds without per-step validity state (padded K-major rows, union slabs) prefetch TWO K-steps
@@ -495,7 +552,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                mfma1(acc[i][j], fa0[i][e], fb0[j][e]);
                 if (n < NP) load_to(n, RAL, RBL, CML, ka_, kb_);
                 ++n;
               }
@@ -520,7 +577,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                mfma1(acc[i][j], fa0[i][e], fb0[j][e]);
                 if (n < NP) store_from(n, nxt, RAS, RBS, CMS);
                 ++n;
               }
@@ -561,7 +618,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                mfma1(acc[i][j], fa0[i][e], fb0[j][e]);
                 if (n < NP && PIPE != 4 && PIPE != 5) load_piece(n);
                 ++n;
               }
@@ -587,7 +644,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][e], fb0[j][e], acc[i][j], 0, 0, 0);
+                mfma1(acc[i][j], fa0[i][e], fb0[j][e]);
                 if (n < NP && PIPE != 4 && PIPE != 5) store_piece(n, nxt);
                 ++n;
               }
@@ -609,6 +666,42 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       }
     }
 
+    if constexpr (SWAP) {
+      // C/D layout with swapped ports: row m = lane & 31 of block i, cols n = 8 q + 4 (lane >> 5) + {0..3} of block j
+      const int row = m0 + wm * (BM / T::WM) + fr;
+      const int cbase = n0 + wn * (BN / T::WN) + 4 * fh;
+      if (nsteps == ksteps) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = row + i * 32;
+          if (r < M) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int col = cbase + j * 32 + 8 * q;
+                const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (col + 3 < N) epi.vec(r, col, v);
+                else {
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    if (col + c < N) epi(r, col + c, v[c]);
+                }
+              }
+          }
+        }
+      } else {
+        // partial K range: park the raw accumulators as 16-byte vectors, register-major (1 KB per wave-instruction)
+        f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              sp[((i * TN + j) * 4 + q) * NT] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      }
+    } else
     if (nsteps == ksteps) {
       // ---- whole tile: epilogue.  C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll

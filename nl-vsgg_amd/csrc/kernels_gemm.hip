@@ -65,6 +65,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
     if (force_tile && t != force_tile) continue;
     if (!force_tile && env_gen == 1 && is_dma_tile(t)) continue;
     if (!force_tile && env_gen == 2 && !is_dma_tile(t)) continue;
+    if (!force_tile && env_gen != 2 && is_dma_tile(t)) continue;      // gemm_dma.h measured slower: opt-in only
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -116,12 +117,19 @@ static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A
   bool split = false;
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
+  // more than one workgroup per CU: the second-dispatched ones walk their work in the opposite order (see the kernel)
+  static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
+  const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
-                     sp.g_sk, base, rem, slab, epi);
+                     sp.g_sk, base, rem, half, slab, epi);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !split) return e;
-  hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn, ksteps,
-                     sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
+  if constexpr (EpiTraits<Epi>::swap)
+    hipLaunchKernelGGL((gemm_dma_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
+                       ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
+  else
+    hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
+                       ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
   return hipGetLastError();
 }
 
@@ -217,8 +225,16 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
     if (epi_vectorizable(epi, N)) return gemm_dma_generic<EpiLinearV>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
     return gemm_dma_generic<EpiScalar4<EpiLinear>>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
   }
-  return padded ? gemm_generic<EpiLinear, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab)
-                : gemm_generic<EpiLinear, B_KMAJOR>(s, A, B, M, N, K, epi, plan, slab);
+  // swapped MFMA ports + 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
+  static const int env_vec = getenv("STTRAN_GEMM_VEC") ? atoi(getenv("STTRAN_GEMM_VEC")) : 1;
+  if (env_vec == 0)
+    return padded ? gemm_generic<EpiLinear, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab)
+                  : gemm_generic<EpiLinear, B_KMAJOR>(s, A, B, M, N, K, epi, plan, slab);
+  if (epi_vectorizable(epi, N))
+    return padded ? gemm_generic<EpiLinearV, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab)
+                  : gemm_generic<EpiLinearV, B_KMAJOR>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
+  return padded ? gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab)
+                : gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
 }
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
