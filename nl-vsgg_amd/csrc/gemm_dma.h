@@ -221,48 +221,4 @@ gemm_dma_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, 
   }
 }
 
-// Sums the parked partial accumulators of every split tile in ascending workgroup order and runs the epilogue.
-// grid = (tiles_sk, TM * TN * 4): one workgroup per 16-byte register group of a tile.
-template <class T, class Epi>
-__global__ void __launch_bounds__(T::NT)
-gemm_dma_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
-                      const float* __restrict__ slab, Epi epi) {
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TN = T::TN;
-  const int tile = blockIdx.x;
-  const int t0 = tile * ksteps, t1 = t0 + ksteps;
-  const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t1 - 1, sk_base, sk_rem);
-  if (b_lo == b_hi) return;                      // computed whole by one workgroup: nothing parked
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / T::WN, wn = wave % T::WN, fr = lane & 31, fh = lane >> 5;
-  const int ijq = blockIdx.y, q = ijq & 3, ij = ijq >> 2, i = ij / TN, j = ij % TN;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const f32x4* base = reinterpret_cast<const f32x4*>(slab) + (int64_t)ijq * NT + tid;
-  for (int b = b_lo; b <= b_hi; b += 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int bb = b + u;
-      const bool ok = bb <= b_hi;
-      const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
-      const f32x4* sp = base + ((int64_t)(ok ? bb : b_lo) * 2 + slot) * (BM * BN / 4);
-      v[u] = ok ? *sp : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
-  }
-  const int gt = tiles_dp + tile;
-  int tile_m, tile_n;
-  tile_origin<T::GROUP_N>(gt, tiles_m, tiles_n, tile_m, tile_n);
-  const int row = tile_m * BM + wm * (BM / T::WM) + i * 32 + fr;
-  const int col = tile_n * BN + wn * (BN / T::WN) + j * 32 + 8 * q + 4 * fh;
-  if (row < M) {
-    if (col + 3 < N) epi.vec(row, col, acc);
-    else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (col + c < N) epi(row, col + c, acc[c]);
-    }
-  }
-}
-
 }  // namespace sttran

@@ -66,6 +66,9 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
     if (!force_tile && env_gen == 1 && is_dma_tile(t)) continue;
     if (!force_tile && env_gen == 2 && !is_dma_tile(t)) continue;
     if (!force_tile && env_gen != 2 && is_dma_tile(t)) continue;      // gemm_dma.h measured slower: opt-in only
+#ifndef STTRAN_GEMM_DMA
+    if (is_dma_tile(t)) continue;
+#endif
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -90,14 +93,24 @@ size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N) {
 }
 
 size_t gemm_slab_floats_max() {
-  size_t m = 0;
-  for (int t = 1; t < TILE_COUNT; ++t) m = std::max(m, gemm_slab_floats(GemmPlan{t, 1}, 0, 0));
-  return m;
+  static size_t cached[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!cached[dev]) {
+    size_t m = 0;
+    for (int t = 1; t < TILE_COUNT; ++t) m = std::max(m, gemm_slab_floats(GemmPlan{t, 1}, 0, 0));
+    cached[dev] = (m + 63) & ~size_t(63);
+  }
+  return cached[dev];
 }
+size_t gemm_slab_bytes() { return gemm_slab_floats_max() * 4 + (size_t)kSkCounters * 4; }
 
 #ifndef STTRAN_GEMM_PIPE
 #define STTRAN_GEMM_PIPE 1
 #endif
+
+// In-launch reduction of the stream-K partials (gemm_f32_mfma.h): one arrival counter per stream-K tile, kept behind the
+// park space (gemm_slab_floats_max() floats, then kSkCounters ints; zeroed at allocation, reset by each reducer).
+static int* sk_counters(float* slab) { return reinterpret_cast<int*>(slab + gemm_slab_floats_max()); }
 
 template <class T, class Epi, int PIPE>
 static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
@@ -120,12 +133,14 @@ static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A
   // more than one workgroup per CU: the second-dispatched ones walk their work in the opposite order (see the kernel)
   static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
   const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
+  static const int env_inlaunch = getenv("STTRAN_GEMM_INLAUNCH") ? atoi(getenv("STTRAN_GEMM_INLAUNCH")) : 1;
+  const bool inlaunch = EpiTraits<Epi>::swap && env_inlaunch && split && sp.tiles_sk <= kSkCounters;
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
-                     sp.g_sk, base, rem, half, slab, epi);
+                     sp.g_sk, base, rem, half, slab, inlaunch ? sk_counters(slab) : nullptr, epi);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !split) return e;
+  if (e != hipSuccess || !split || inlaunch) return e;
   if constexpr (EpiTraits<Epi>::swap)
-    hipLaunchKernelGGL((gemm_dma_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
+    hipLaunchKernelGGL((gemm_fixup_vec_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
                        ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
   else
     hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
@@ -151,7 +166,8 @@ static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, 
 #endif
 }
 
-// ---- gemm_dma.h launch ----------------------------------------------------------------------------------------
+// ---- gemm_dma.h launch (experiment: built only with EXTRA=-DSTTRAN_GEMM_DMA) ------------------------------------
+#ifdef STTRAN_GEMM_DMA
 template <class T, class Epi>
 static hipError_t launch_dma_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
                                   int K, float* slab, const Epi& epi) {
@@ -176,7 +192,7 @@ static hipError_t launch_dma_tile(hipStream_t s, int tile_id, const GemmOperand&
                      sp.g_sk, base, rem, half, slab, epi);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || !split) return e;
-  hipLaunchKernelGGL((gemm_dma_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
+  hipLaunchKernelGGL((gemm_fixup_vec_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
                      ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
   return hipGetLastError();
 }
@@ -194,6 +210,8 @@ static hipError_t gemm_dma_generic(hipStream_t s, const GemmOperand& A, const Ge
     default: return launch_dma_tile<DmaTile<64, 64, 2, 2>, Epi>(s, TILE_D64x64, A, B, M, N, K, slab, epi);
   }
 }
+
+#endif  // STTRAN_GEMM_DMA
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // can EpiLinear run as 16-byte vectors?  (every pointer it dereferences at a column that is a multiple of 4)
@@ -221,27 +239,25 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
                        const EpiLinear& epi, GemmPlan plan, float* slab, int padded) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if (is_dma_tile(plan.tile)) {
+#ifdef STTRAN_GEMM_DMA
     if (!padded) return hipErrorInvalidValue;
     if (epi_vectorizable(epi, N)) return gemm_dma_generic<EpiLinearV>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
     return gemm_dma_generic<EpiScalar4<EpiLinear>>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
+#else
+    return hipErrorInvalidValue;
+#endif
   }
-  // swapped MFMA ports + 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
-  static const int env_vec = getenv("STTRAN_GEMM_VEC") ? atoi(getenv("STTRAN_GEMM_VEC")) : 1;
-  if (env_vec == 0)
-    return padded ? gemm_generic<EpiLinear, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab)
-                  : gemm_generic<EpiLinear, B_KMAJOR>(s, A, B, M, N, K, epi, plan, slab);
-  if (epi_vectorizable(epi, N))
-    return padded ? gemm_generic<EpiLinearV, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab)
-                  : gemm_generic<EpiLinearV, B_KMAJOR>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
-  return padded ? gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab)
-                : gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
+  // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
+  // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
+  if (!padded) return gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
+  if (epi_vectorizable(epi, N)) return gemm_generic<EpiLinearV, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
+  return gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
 }
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
-  if (is_dma_tile(plan.tile))
-    return gemm_dma_generic<EpiScalar4<EpiHeads>>(s, A, B, M, N, K, EpiScalar4<EpiHeads>{epi}, plan, slab);
-  return gemm_generic<EpiHeads, B_KMAJOR_PAD>(s, A, B, M, N, K, epi, plan, slab);     // product only: padded operands
+  if (is_dma_tile(plan.tile)) return hipErrorInvalidValue;
+  return gemm_generic<EpiScalar4<EpiHeads>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiHeads>{epi}, plan, slab);   // padded operands
 }
 // union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K
 // over (tile, K-step) like every other GEMM

@@ -255,9 +255,9 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
                int force_tile = 0, int force_split = 0) {
   if (M <= 0) return STTRAN_OK;
   GemmPlan plan = plan_gemm(M, N, K, force_tile, force_split);
-  if (gemm_slab_floats_max() * 4 > h->slab.bytes) {
+  if (gemm_slab_bytes() > h->slab.bytes) {
     HIPCK(hipStreamSynchronize(s));
-    HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
+    HIPCK(h->slab.ensure(gemm_slab_bytes()));
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
@@ -316,7 +316,7 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   // 128-byte lines, and the 16 pad columns -- zeroed here, never written by any kernel -- are what the GEMM A loader
   // reads for the K tail (B_KMAJOR_PAD), so nothing a previous call left behind can reach a later call's result.
   const int64_t D = h->cfg.embed_dim, LD = pad32(D), F = h->cfg.ffn_dim, tok = 2 * cp;
-  HIPCK(h->slab.ensure(gemm_slab_floats_max() * 4));
+  HIPCK(h->slab.ensure(gemm_slab_bytes()));
   HIPCK(h->x0.ensure((size_t)cp * LD * 4));
   HIPCK(h->ebuf.ensure((size_t)cp * LD * 4));
   HIPCK(h->qkv.ensure((size_t)tok * 3 * D * 4));
@@ -1035,7 +1035,8 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   GemmPlan plan = plan_gemm(M, N, K, tile_cfg, split_k);
   static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
-  if (!slab && hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_floats_max() * 4) != hipSuccess)
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess ||
+                hipMemset(slab, 0, gemm_slab_bytes()) != hipSuccess))
     return STTRAN_ERR_HIP;
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
@@ -1054,7 +1055,8 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   GemmPlan plan = plan_gemm(M, N, K, tile_cfg, 0);
   static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
-  if (!slab && hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_floats_max() * 4) != hipSuccess)
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess ||
+                hipMemset(slab, 0, gemm_slab_bytes()) != hipSuccess))
     return STTRAN_ERR_HIP;
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;

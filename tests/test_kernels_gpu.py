@@ -216,3 +216,32 @@ def test_attention_spiked_scores(lib):
     ref = _attn_ref(qkv, [0], [L], dim, nhead)
     assert torch.isfinite(out).all()
     assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(330, 1936, 1936, 4), (176, 5808, 1936, 3), (2816, 1936, 1936, 1), (5280, 2048, 1936, 1),
+                                        (700, 512, 12544, 2), (330, 1936, 2048, 0)])
+def test_gemm_inlaunch_reduction_stress(lib, M, N, K, tile):
+    """stream-K tiles are reduced inside the launch by their last-arriving workgroup (sc1 write-through parking, one
+    agent-scope arrival counter per tile, one acquire in the reducer).  A stale read of a parked line -- from this CU's
+    L1 or this XCD's L2, which hold the PREVIOUS launch's partials at the same addresses -- would return the previous
+    problem's numbers: every launch here has fresh operands, is checked against an fp64 reference, and is repeated to
+    check that the result does not depend on which workgroup arrived last (bit-identical)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + tile)
+    Kp = (K + 31) // 32 * 32
+    W = torch.zeros(N, Kp, device="cuda")
+    b = torch.randn(N, device="cuda", generator=g)
+    tol = 1e-5 * (K ** 0.5) * 12 + 1e-5
+    for it in range(40):
+        A = torch.randn(M + 1, Kp, device="cuda", generator=g) * (1.0 + it)       # scale changes: stale sums stand out
+        W[:, :K] = torch.randn(N, K, device="cuda", generator=g)
+        res = torch.randn(M, N, device="cuda", generator=g)
+        outs = []
+        for rep in range(3):
+            Cc = torch.full((M, N), float("nan"), device="cuda")
+            assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(W), Kp, _p(b), _p(res), _p(Cc), M, N, K, 0, tile, None) == 0
+            outs.append(Cc)
+        torch.cuda.synchronize()
+        ref = _ref(A[:M, :K], W[:, :K], b, res)
+        err = (outs[0].double() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item() / (K ** 0.5)), (it, err)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), it
