@@ -197,7 +197,7 @@ struct GemmTile {
   static constexpr int BV = BKIND == B_UNION ? (kUStageB / 4 + NT - 1) / NT : BN * 8 / NT;
   static constexpr int STAGE_B = BKIND == B_UNION ? kUStageB : BN * kLdsStride;
   static constexpr int STAGE = BM * kLdsStride + STAGE_B;              // floats per LDS stage
-  static constexpr int LDS_BYTES = 2 * STAGE * 4 + 16;                 // + one word: "this workgroup reduces the tile"
+  static constexpr int LDS_BYTES = 2 * STAGE * 4;
   static constexpr int GROUP_N = BKIND == B_UNION ? 1 : 8;            // tile_origin: N-tiles per group
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
   static_assert((BM * 8) % NT == 0, "A staging must divide evenly");
@@ -252,7 +252,7 @@ __host__ __device__ __forceinline__ int sk_owner(int it, int base, int rem) {
 template <class T, class Epi, int PIPE>
 __global__ void __launch_bounds__(T::NT)
 gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
-               int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, int* __restrict__ sk_count, Epi epi) {
+               int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
   constexpr bool UNION = T::BKIND == B_UNION;
@@ -690,9 +690,11 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
               }
           }
         }
-      } else if (!sk_count) {
+      } else {
         // partial K range: park the raw accumulators as 16-byte vectors, register-major (1 KB per wave-instruction);
-        // gemm_fixup_vec_kernel sums them
+        // gemm_fixup_vec_kernel sums them.  (Reducing them inside the launch -- write-through parking, an arrival
+        // counter per tile, the last arriver sums -- was built and measured: correct, but slower than this fix-up
+        // launch at every size)
         f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -701,89 +703,6 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               sp[((i * TN + j) * 4 + q) * NT] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-      } else {
-        // ---- partial K range, reduced INSIDE the launch by the tile's last-arriving workgroup (no fix-up launch).
-        // Hand-off form (cdna_hip_programming.md Guideline 16, R1 with an arrival counter; MI355X_MICROARCH.md
-        // "Valid forms"): every contributor parks its accumulators WRITE-THROUGH (sc1 stores: the bytes leave this
-        // XCD's L2, so no release fence), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup
-        // meets at a barrier, ONE lane adds 1 to the tile's counter (agent-scope atomic).  The workgroup whose add
-        // returns contributors - 1 is the last: that lane runs ONE agent-scope acquire (drops stale copies of the
-        // parked lines from this CU's L1 / this XCD's L2), waits for it, resets the counter for the next launch and
-        // tells its workgroup through an LDS word behind a barrier.  The reducer then sums ALL contributions -- its
-        // own included, re-read from the slab -- in ascending workgroup order, exactly as the fix-up kernel does, so
-        // the result does not depend on who arrived last (bit-identical to the two-launch path).  Nobody waits or
-        // spins: correctness does not depend on dispatch order, timing or workgroup -> XCD placement.
-        f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(sp + ((i * TN + j) * 4 + q) * NT), "v"(v) : "memory");
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its own stores
-        __syncthreads();
-        const int tsk = tile - tiles_dp;                            // index inside the stream-K region
-        const int t0 = tsk * ksteps;
-        const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t0 + ksteps - 1, sk_base, sk_rem);
-        int* flag = reinterpret_cast<int*>(smem + 2 * T::STAGE);
-        if (tid == 0) {
-          const int old = __hip_atomic_fetch_add(sk_count + tsk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int last = old == b_hi - b_lo;
-          if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the invalidate has completed
-            __hip_atomic_store(sk_count + tsk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-          }
-          *flag = last;
-        }
-        __syncthreads();
-        if (*flag) {                                                // workgroup-uniform
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-              for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-          for (int b = b_lo; b <= b_hi; ++b) {
-            // workgroup b parked this tile in slot 1 if its range started in an earlier tile (only b_lo can), else 0
-            const int slot = (b == b_lo && sk_range(b, sk_base, sk_rem).begin < t0) ? 1 : 0;
-            const f32x4* cp = reinterpret_cast<const f32x4*>(slab + ((int64_t)b * 2 + slot) * (BM * BN)) + tid;
-            f32x4 v[TM * TN * 4];
-#pragma unroll
-            for (int u = 0; u < TM * TN * 4; ++u) v[u] = cp[u * NT];      // plain vector loads: valid behind the acquire
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                  for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] += v[(i * TN + j) * 4 + q][c];
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int r = row + i * 32;
-            if (r < M) {
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const int col = cbase + j * 32 + 8 * q;
-                  const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                  if (col + 3 < N) epi.vec(r, col, v);
-                  else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                      if (col + c < N) epi(r, col + c, v[c]);
-                  }
-                }
-            }
-          }
-        }
-        __syncthreads();                                            // the flag word is rewritten by the next segment
       }
     } else
     if (nsteps == ksteps) {
@@ -869,8 +788,7 @@ gemm_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, 
 }
 
 // The same for the swapped-port (vector) accumulator layout: sums the parked 16-byte vectors of every split tile in
-// ascending workgroup order and runs the vector epilogue.  Used when the in-launch reduction is switched off.
-// grid = (tiles_sk, TM * TN * 4): one workgroup per 16-byte register group of a tile.
+// ascending workgroup order and runs the vector epilogue.  // grid = (tiles_sk, TM * TN * 4): one workgroup per 16-byte register group of a tile.
 template <class T, class Epi>
 __global__ void __launch_bounds__(T::NT)
 gemm_fixup_vec_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,

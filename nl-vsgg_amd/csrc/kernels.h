@@ -41,8 +41,7 @@ struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
 size_t gemm_slab_floats_max();   // park space of the stream-K schedule, any tile
-constexpr int kSkCounters = 4096; // arrival counters of the in-launch stream-K reduction (one per stream-K tile)
-size_t gemm_slab_bytes();        // park space + counters: what a `slab` argument must point to (zero-initialised)
+size_t gemm_slab_bytes();        // what a `slab` argument must point to
 
 // padded: both operands can be read up to ceil32(K) columns per row and B is zero there (gemm_f32_mfma.h, B_KMAJOR_PAD)
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,

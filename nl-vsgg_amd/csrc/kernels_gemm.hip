@@ -1,9 +1,5 @@
 // kernels_gemm.hip -- instantiations, tile planning and launchers of the fp32 MFMA GEMM.
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-
-#include "kernels.h"
+#include "gemm_launch.h"
 
 namespace sttran {
 
@@ -15,17 +11,6 @@ using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
 using TConv2 = GemmTile<256, 128, 4, 2, B_CONV2>;   // conv3x3 as implicit GEMM: all 256 output channels in one tile (B gathered once)
 using TUnion = GemmTile<128, 256, 2, 4, B_UNION>;   // 8 waves, wave tile 64x64, B = NCHW union_feat slabs
 
-struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
-// eff = fraction of the fp32-MFMA peak the tile's main loop sustains on a large square problem
-// (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
-// (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
-static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
-    {128, 256, 0.80f, 1},    // TILE_UNION (never chosen by plan_gemm)
-    // gemm_dma.h tiles: LDS = 64 / 96 / 48 / 32 KB per workgroup
-    {128, 128, 0.92f, 2}, {256, 128, 0.92f, 1}, {128, 64, 0.88f, 3}, {64, 64, 0.80f, 4}};
-static bool is_dma_tile(int t) { return t >= TILE_D128x128 && t <= TILE_D64x64; }
-
 int num_cus() {
   static int cus[kMaxDevices] = {};
   const int dev = current_device();
@@ -36,21 +21,6 @@ int num_cus() {
   }
   return n;
 }
-
-// Hybrid data-parallel + stream-K schedule of one GEMM: G persistent workgroups each run dp_per_wg whole
-// tiles; the tiles_sk leftover tiles (< G) are cut into g_sk equal iteration ranges.
-struct SkPlan { int G, dp_per_wg, tiles_sk, g_sk; };
-static SkPlan sk_plan(int tile, int64_t tiles, int64_t ksteps) {
-  const int64_t g = (int64_t)num_cus() * kTiles[tile].blocks_per_cu;
-  SkPlan p;
-  p.G = (int)std::min<int64_t>(g, std::max<int64_t>(1, tiles * ksteps / 4));
-  p.dp_per_wg = (int)(tiles / p.G);
-  p.tiles_sk = (int)(tiles - (int64_t)p.dp_per_wg * p.G);
-  // never cut finer than 4 K-steps per workgroup: below that the per-segment prologue dominates
-  p.g_sk = (int)std::max<int64_t>(p.tiles_sk ? 1 : 0, std::min<int64_t>(p.G, (int64_t)p.tiles_sk * ksteps / 4));
-  return p;
-}
-static int grid_of(int tile, int64_t tiles, int64_t ksteps) { return sk_plan(tile, tiles, ksteps).G; }
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split) {
   (void)force_split;   // split-K is subsumed by the stream-K schedule
@@ -102,69 +72,7 @@ size_t gemm_slab_floats_max() {
   }
   return cached[dev];
 }
-size_t gemm_slab_bytes() { return gemm_slab_floats_max() * 4 + (size_t)kSkCounters * 4; }
-
-#ifndef STTRAN_GEMM_PIPE
-#define STTRAN_GEMM_PIPE 1
-#endif
-
-// In-launch reduction of the stream-K partials (gemm_f32_mfma.h): one arrival counter per stream-K tile, kept behind the
-// park space (gemm_slab_floats_max() floats, then kSkCounters ints; zeroed at allocation, reset by each reducer).
-static int* sk_counters(float* slab) { return reinterpret_cast<int*>(slab + gemm_slab_floats_max()); }
-
-template <class T, class Epi, int PIPE>
-static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
-                                int K, float* slab, const Epi& epi) {
-  static DeviceMarks marks;
-  auto kern = gemm_sk_kernel<T, Epi, PIPE>;
-  {
-    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
-    if (e != hipSuccess) return e;
-  }
-  const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
-  const int ksteps = (K + kBK - 1) / kBK;
-  const SkPlan sp = sk_plan(tile_id, tiles, ksteps);
-  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
-  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
-  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
-  bool split = false;
-  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
-  if (split && !slab) return hipErrorInvalidValue;
-  // more than one workgroup per CU: the second-dispatched ones walk their work in the opposite order (see the kernel)
-  static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
-  const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
-  static const int env_inlaunch = getenv("STTRAN_GEMM_INLAUNCH") ? atoi(getenv("STTRAN_GEMM_INLAUNCH")) : 1;
-  const bool inlaunch = EpiTraits<Epi>::swap && env_inlaunch && split && sp.tiles_sk <= kSkCounters;
-  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
-                     sp.g_sk, base, rem, half, slab, inlaunch ? sk_counters(slab) : nullptr, epi);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !split || inlaunch) return e;
-  if constexpr (EpiTraits<Epi>::swap)
-    hipLaunchKernelGGL((gemm_fixup_vec_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
-                       ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
-  else
-    hipLaunchKernelGGL((gemm_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
-                       ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
-  return hipGetLastError();
-}
-
-template <class T, class Epi>
-static hipError_t launch_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
-                              int K, float* slab, const Epi& epi) {
-#ifdef STTRAN_GEMM_EXPERIMENT
-  // build-time experiment switch (tools/gemm_bench.py): pick the main-loop variant at run time
-  const char* v = getenv("STTRAN_GEMM_PIPE");
-  const int pipe = v ? atoi(v) : STTRAN_GEMM_PIPE;
-  if (pipe == 1) return launch_tile_p<T, Epi, 1>(s, tile_id, A, B, M, N, K, slab, epi);
-  if (pipe == 2) return launch_tile_p<T, Epi, 2>(s, tile_id, A, B, M, N, K, slab, epi);
-  if (pipe == 3) return launch_tile_p<T, Epi, 3>(s, tile_id, A, B, M, N, K, slab, epi);
-  if (pipe == 4) return launch_tile_p<T, Epi, 4>(s, tile_id, A, B, M, N, K, slab, epi);
-  if (pipe == 5) return launch_tile_p<T, Epi, 5>(s, tile_id, A, B, M, N, K, slab, epi);
-  return launch_tile_p<T, Epi, 0>(s, tile_id, A, B, M, N, K, slab, epi);
-#else
-  return launch_tile_p<T, Epi, STTRAN_GEMM_PIPE>(s, tile_id, A, B, M, N, K, slab, epi);
-#endif
-}
+size_t gemm_slab_bytes() { return gemm_slab_floats_max() * 4; }
 
 // ---- gemm_dma.h launch (experiment: built only with EXTRA=-DSTTRAN_GEMM_DMA) ------------------------------------
 #ifdef STTRAN_GEMM_DMA
@@ -221,18 +129,6 @@ static bool epi_vectorizable(const EpiLinear& e, int N) {
          (e.ldres & 3) == 0;
 }
 
-template <class Epi, int BK>
-static hipError_t gemm_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                               const Epi& epi, GemmPlan plan, float* slab) {
-  if (M <= 0 || N <= 0) return hipSuccess;
-  switch (plan.tile) {
-    case TILE_256x128: return launch_tile<GemmTile<256, 128, 4, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_128x128: return launch_tile<GemmTile<128, 128, 2, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_128x64: return launch_tile<GemmTile<128, 64, 2, 2, BK>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    default: return launch_tile<GemmTile<64, 64, 2, 2, BK>, Epi>(s, TILE_64x64, A, B, M, N, K, slab, epi);
-  }
-}
-
 // padded != 0: the operands meet the B_KMAJOR_PAD contract (gemm_f32_mfma.h); rows must then be 128-byte multiples apart
 // only as far as the caller's ld says -- what matters is that ceil32(K) columns of every row are readable.
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
@@ -249,15 +145,16 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
   }
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
-  if (!padded) return gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
-  if (epi_vectorizable(epi, N)) return gemm_generic<EpiLinearV, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
-  return gemm_generic<EpiScalar4<EpiLinear>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
+  if (!padded) return gemm_linear_sel(s, A, B, M, N, K, epi, plan, slab);
+  if (epi_vectorizable(epi, N)) return gemm_linear_vec(s, A, B, M, N, K, epi, plan, slab);
+  return gemm_linear_s4(s, A, B, M, N, K, epi, plan, slab);
 }
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if (is_dma_tile(plan.tile)) return hipErrorInvalidValue;
-  return gemm_generic<EpiScalar4<EpiHeads>, B_KMAJOR_PAD>(s, A, B, M, N, K, EpiScalar4<EpiHeads>{epi}, plan, slab);   // padded operands
+  // N = 26: only the 64x64 tile makes sense (sttran_api.hip forces it); padded operands
+  return launch_tile<GemmTile<64, 64, 2, 2, B_KMAJOR_PAD>, EpiScalar4<EpiHeads>>(s, TILE_64x64, A, B, M, N, K, slab, EpiScalar4<EpiHeads>{epi});
 }
 // union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K
 // over (tile, K-step) like every other GEMM

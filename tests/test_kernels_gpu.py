@@ -220,12 +220,10 @@ def test_attention_spiked_scores(lib):
 
 @pytest.mark.parametrize("M,N,K,tile", [(330, 1936, 1936, 4), (176, 5808, 1936, 3), (2816, 1936, 1936, 1), (5280, 2048, 1936, 1),
                                         (700, 512, 12544, 2), (330, 1936, 2048, 0)])
-def test_gemm_inlaunch_reduction_stress(lib, M, N, K, tile):
-    """stream-K tiles are reduced inside the launch by their last-arriving workgroup (sc1 write-through parking, one
-    agent-scope arrival counter per tile, one acquire in the reducer).  A stale read of a parked line -- from this CU's
-    L1 or this XCD's L2, which hold the PREVIOUS launch's partials at the same addresses -- would return the previous
-    problem's numbers: every launch here has fresh operands, is checked against an fp64 reference, and is repeated to
-    check that the result does not depend on which workgroup arrived last (bit-identical)."""
+def test_gemm_stream_k_reuse_stress(lib, M, N, K, tile):
+    """stream-K partial tiles are parked in a slab that every launch reuses and summed by the fix-up launch: fresh
+    operands on every launch, an fp64 reference, and three repeats that must agree bit for bit (fixed summation order;
+    nothing from the previous problem may leak through the park space)."""
     g = torch.Generator(device="cuda").manual_seed(M + N + K + tile)
     Kp = (K + 31) // 32 * 32
     W = torch.zeros(N, Kp, device="cuda")
