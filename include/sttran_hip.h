@@ -195,6 +195,55 @@ int sttran_eval_recall(const SttranEvalInputs* in, uint8_t* flags, int32_t* stat
 /* most pairs one frame may have for the given number of predicate columns (26 -> 96) */
 int32_t sttran_eval_max_pairs(int32_t num_predicates);
 
+/* SGDet WITHOUT weak supervision: the `else` branch of `ObjectClassifier.forward`, lib/sttran.py:185-283,
+ * i.e. what runs in front of the relation transformer when `STTran(mode='sgdet', is_wks=False)` is in eval mode.
+ *
+ * sttran_objcls_select: `clean_class` for classes 5, 8, 17 (:52-85,197-199); per frame and per class (arg-max of the
+ * distribution) greedy NMS at `nms_threshold` in descending score order (:203-237; the `nms` op is
+ * fasterRCNN/lib/model/csrc/cuda/nms.cu:13-131 -- IoU with +1 pixel extents, suppression on IoU > threshold;
+ * `nms_ge` != 0 selects the >= of cpu/nms_cpu.cpp:62); `pred_scores` / `pred_labels` = max / arg-max + 2 over columns
+ * 1.. (:243-244); `human_idx` = per frame the row with the largest column-0 score, 0 for a frame without boxes, whose
+ * label becomes 1 and whose score becomes that column-0 value (:247-254, the empty-frame assignment to row 0 included);
+ * pairs (human of the frame, every other-labelled box of the frame) in frame order (:256-268).
+ * Inputs are device pointers; `boxes` [B,5] must be sorted by frame id (column 0).  Every output array must hold
+ * `capacity` >= 8 * num_boxes rows (each clean_class pass can at most double a frame's boxes; NMS only removes).
+ * The output sizes are data dependent: the call synchronises the stream ONCE and returns them through
+ * *num_boxes_out / *num_pairs_out (the reference synchronises dozens of times in this branch).
+ * `out_source_row` (optional) tells which input row each output box is a copy of. */
+typedef struct SttranObjclsSelect {
+  uint32_t struct_size;          /* = sizeof(SttranObjclsSelect) */
+  int32_t num_frames;            /* b = int(boxes[-1, 0] + 1)                         */
+  int64_t num_boxes;             /* B                                                 */
+  int32_t num_cols;              /* columns of `distribution` = len(obj_classes) - 1  */
+  int32_t feat_dim;              /* columns of `features` (0 with features == NULL)   */
+  float nms_threshold;           /* 0.6 (lib/sttran.py:227)                           */
+  int32_t nms_ge;                /* 0: IoU > thr (nms.cu, what the reference runs); 1: IoU >= thr (nms_cpu.cpp) */
+  const float* boxes;            /* [B,5]                 entry['boxes']              */
+  const float* distribution;     /* [B,num_cols]          entry['distribution']       */
+  const float* features;         /* [B,feat_dim] or NULL  entry['features']           */
+  const int64_t* pred_labels;    /* [B]                   entry['pred_labels'] (the detector's) */
+  int64_t capacity;              /* rows of every out_* array, >= 8 * num_boxes       */
+  float* out_boxes;              /* [capacity,5]                                      */
+  float* out_distribution;       /* [capacity,num_cols]                               */
+  float* out_features;           /* [capacity,feat_dim] or NULL                       */
+  float* out_pred_scores;        /* [capacity]                                        */
+  int64_t* out_pred_labels;      /* [capacity]                                        */
+  int32_t* out_source_row;       /* [capacity] or NULL                                */
+  int64_t* out_pair_idx;         /* [capacity,2]                                      */
+  float* out_im_idx;             /* [capacity]                                        */
+  int64_t* out_human_idx;        /* [num_frames]                                      */
+  void* scratch;                 /* sttran_objcls_scratch_bytes(num_boxes, num_frames) bytes of device memory */
+  int64_t scratch_bytes;
+} SttranObjclsSelect;
+int64_t sttran_objcls_scratch_bytes(int64_t num_boxes, int32_t num_frames);
+int sttran_objcls_select(const SttranObjclsSelect* args, int64_t* num_boxes_out, int64_t* num_pairs_out, void* stream);
+/* `RCNN_roi_align(entry['fmaps'], union_boxes)`, lib/sttran.py:36,275: ROIAlign forward of
+ * fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:65-118 (no coordinate rounding, adaptive sampling grid when
+ * sampling_ratio <= 0, bilinear samples averaged per bin).  fmaps [T,C,H,W], rois [P,5] (frame index, x1,y1,x2,y2),
+ * out [P,C,pooled,pooled]; device pointers; enqueue only. */
+int sttran_roi_align(const float* fmaps, int32_t T, int32_t C, int32_t H, int32_t W, const float* rois, int64_t num_rois,
+                     int32_t pooled, float spatial_scale, int32_t sampling_ratio, float* out, void* stream);
+
 /* profiling (no reference counterpart; SURVEY 5 "Tracing / profiling: none") */
 int sttran_profile_enable(SttranHandle* h, int32_t enable);
 int sttran_profile_reset(SttranHandle* h);

@@ -72,6 +72,16 @@ class SttranEvalInputs(C.Structure):
                 ("gt_rel_off", C.c_void_p), ("gt_rels", C.c_void_p)]
 
 
+class SttranObjclsSelect(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("num_frames", C.c_int32), ("num_boxes", C.c_int64),
+                ("num_cols", C.c_int32), ("feat_dim", C.c_int32), ("nms_threshold", C.c_float), ("nms_ge", C.c_int32),
+                ("boxes", C.c_void_p), ("distribution", C.c_void_p), ("features", C.c_void_p), ("pred_labels", C.c_void_p),
+                ("capacity", C.c_int64), ("out_boxes", C.c_void_p), ("out_distribution", C.c_void_p),
+                ("out_features", C.c_void_p), ("out_pred_scores", C.c_void_p), ("out_pred_labels", C.c_void_p),
+                ("out_source_row", C.c_void_p), ("out_pair_idx", C.c_void_p), ("out_im_idx", C.c_void_p),
+                ("out_human_idx", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
+
+
 # every symbol include/sttran_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("sttran_create", C.c_int, [C.POINTER(SttranConfig), C.POINTER(C.c_void_p)]),
@@ -93,6 +103,10 @@ SYMBOLS = [
                                            C.c_void_p, C.c_void_p]),
     ("sttran_eval_recall", C.c_int, [C.POINTER(SttranEvalInputs), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("sttran_eval_max_pairs", C.c_int32, [C.c_int32]),
+    ("sttran_objcls_scratch_bytes", C.c_int64, [C.c_int64, C.c_int32]),
+    ("sttran_objcls_select", C.c_int, [C.POINTER(SttranObjclsSelect), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    ("sttran_roi_align", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                   C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     ("sttran_debug_gemm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("sttran_debug_gemm_padded", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -105,4 +105,15 @@ hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float*
                               const float* pos_w, const float* pos_b, float* z, int64_t ldz, int B, int feat_dim,
                               int ncls, int emb_dim);
 
+// ---- SGDet without weak supervision (lib/sttran.py:185-283): kernels_objcls.hip ------------------------
+size_t objcls_scratch_bytes(int64_t B, int T);
+// clean_class + per-(frame, class) NMS + labels / scores / human / pairs.  Outputs need 8 * B rows (pairs: 8 * B too).
+// Synchronises `s` once to return {rows, pairs, status} in host_out.
+hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* dist, const float* feats,
+                                const int64_t* labels, int64_t B, int T, int ncol, int F, float thr, int ge, int64_t capacity,
+                                float* o_boxes, float* o_dist, float* o_feats, float* o_score, int64_t* o_label, int* o_src,
+                                int64_t* o_pair, float* o_im, int64_t* o_human, void* scratch, int32_t host_out[3]);
+hipError_t launch_roi_align(hipStream_t s, const float* fmaps, int T, int C, int H, int W, const float* rois, int64_t P,
+                            int pooled, float spatial_scale, int sampling_ratio, float* out);
+
 }  // namespace sttran

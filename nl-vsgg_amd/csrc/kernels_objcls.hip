@@ -1,0 +1,374 @@
+// kernels_objcls.hip -- SURVEY 8f-2: the ObjectClassifier branch of SGDet WITHOUT weak supervision
+// (lib/sttran.py:185-283): clean_class (:52-85), per-(frame, class) greedy NMS at 0.6 (:203-237 with
+// fasterRCNN/lib/model/csrc/cuda/nms.cu:13-131), label / score / human selection (:239-254), pair enumeration
+// (:256-268) and ROIAlign of the union boxes on the detector's feature maps (:275 with
+// fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:16-118).
+//
+// Integer / index work plus a little float32 geometry: every float expression below is written with ONE rounding per
+// operation in the statement order of the reference sources (`#pragma clang fp contract(off)`: hipcc fuses a*b+c by
+// default), so keep / pair indices are decided by the same float32 values the reference compares.
+//
+// An expanded box is (source row, zero mask, label): clean_class duplicates a box with one column of its class
+// distribution set to 0, so a duplicate is fully described by the input row it came from and the set of zeroed columns.
+#include <algorithm>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace sttran {
+
+namespace {
+
+constexpr int kOcMaxCols = 64;        // class-distribution columns (36 in the reference)
+constexpr int kOcMaxFrameBoxes = 1024; // expanded boxes per frame the NMS kernel holds in LDS
+
+// arg-max over the columns of a distribution row with the masked columns reading 0 (first maximum wins, like
+// torch.argmax on distinct values)
+__device__ __forceinline__ int argmax_masked(const float* __restrict__ row, int ncol, uint64_t zmask, int first, float* best_out) {
+  int bi = first;
+  float best = ((zmask >> first) & 1) ? 0.f : row[first];
+  for (int c = first + 1; c < ncol; ++c) {
+    const float v = ((zmask >> c) & 1) ? 0.f : row[c];
+    if (v > best) { best = v; bi = c; }
+  }
+  if (best_out) *best_out = best;
+  return bi;
+}
+
+// frame f owns input rows [fstart[f], fstart[f+1]) (boxes are sorted by frame id, as the detector emits them)
+__global__ void objcls_frame_ranges_kernel(const float* __restrict__ boxes, int B, int T, int* __restrict__ fstart) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > T) return;
+  int lo = 0, hi = B;                       // first row whose frame id >= f
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (boxes[(int64_t)mid * 5] < (float)f) lo = mid + 1; else hi = mid;
+  }
+  fstart[f] = lo;
+}
+
+// clean_class(5), clean_class(8), clean_class(17) of one frame per thread (lib/sttran.py:52-85,197-199): after each
+// pass the frame's list is [what it was ..., a copy of every box whose label is the class, with that class's column
+// zeroed and the label re-derived by arg-max].  Capacity 8 x the frame's input boxes (each pass at most doubles).
+__global__ void objcls_expand_kernel(const float* __restrict__ dist, const int64_t* __restrict__ labels, int ncol, int T,
+                                     const int* __restrict__ fstart, int* __restrict__ ent_src, uint64_t* __restrict__ ent_mask,
+                                     int* __restrict__ ent_label, int* __restrict__ n1) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= T) return;
+  const int r0 = fstart[f], r1 = fstart[f + 1];
+  const int64_t base = (int64_t)8 * r0;
+  int n = 0;
+  for (int r = r0; r < r1; ++r, ++n) {
+    ent_src[base + n] = r; ent_mask[base + n] = 0; ent_label[base + n] = (int)labels[r];
+  }
+  const int classes[3] = {5, 8, 17};
+  for (int s = 0; s < 3; ++s) {
+    const int c = classes[s];
+    if (c - 1 >= ncol) continue;
+    const int n_before = n;
+    for (int k = 0; k < n_before; ++k) {
+      if (ent_label[base + k] != c) continue;
+      const int src = ent_src[base + k];
+      const uint64_t m = ent_mask[base + k] | (1ull << (c - 1));
+      ent_src[base + n] = src; ent_mask[base + n] = m;
+      ent_label[base + n] = argmax_masked(dist + (int64_t)src * ncol, ncol, m, 0, nullptr) + 1;
+      ++n;
+    }
+  }
+  n1[f] = n;
+}
+
+// fasterRCNN/lib/model/csrc/cuda/nms.cu:13-21
+__device__ __forceinline__ float dev_iou(const float* a, const float* b) {
+  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+  const float interS = width * height;
+  const float Sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+  const float Sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+  return interS / (Sa + Sb - interS);
+}
+
+// One workgroup per frame: class of every expanded box = arg-max of its (masked) distribution; order by (class
+// ascending, score descending, position ascending) = the order in which lib/sttran.py:211-236 emits the per-class
+// groups; greedy suppression inside each class (nms.cu:96-118: a box is dropped when its IoU with an earlier kept box
+// of the class exceeds the threshold; `ge` selects the CPU flavour's >=, nms_cpu.cpp:62).
+__global__ void __launch_bounds__(256)
+objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dist, int ncol, const int* __restrict__ fstart,
+                  const int* __restrict__ ent_src, const uint64_t* __restrict__ ent_mask, const int* __restrict__ n1,
+                  float thr, int ge, int* __restrict__ kept, int* __restrict__ n2, int* __restrict__ status) {
+  __shared__ float bx[kOcMaxFrameBoxes][4];
+  __shared__ float score[kOcMaxFrameBoxes];
+  __shared__ short cls[kOcMaxFrameBoxes];
+  __shared__ short order[kOcMaxFrameBoxes];
+  __shared__ unsigned char supp[kOcMaxFrameBoxes];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int n = n1[f];
+  const int64_t base = (int64_t)8 * fstart[f];
+  if (n > kOcMaxFrameBoxes) {
+    if (tid == 0) { atomicOr(status, 1); n2[f] = 0; }
+    return;
+  }
+  for (int t = tid; t < n; t += 256) {
+    const int src = ent_src[base + t];
+    float s;
+    cls[t] = (short)argmax_masked(dist + (int64_t)src * ncol, ncol, ent_mask[base + t], 0, &s);
+    score[t] = s;
+    for (int c = 0; c < 4; ++c) bx[t][c] = boxes[(int64_t)src * 5 + 1 + c];
+    supp[t] = 0;
+  }
+  __syncthreads();
+  for (int t = tid; t < n; t += 256) {
+    const int ct = cls[t];
+    const float st = score[t];
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const int cu = cls[u];
+      const float su = score[u];
+      rank += (cu < ct) || (cu == ct && (su > st || (su == st && u < t)));
+    }
+    order[rank] = (short)t;
+  }
+  __syncthreads();
+  for (int p = 0; p < n; ++p) {
+    if (!supp[p]) {                                   // workgroup-uniform: written before the last barrier
+      const int ip = order[p];
+      const int cp = cls[ip];
+      for (int j = p + 1 + tid; j < n; j += 256) {
+        const int ij = order[j];
+        if (cls[ij] != cp) break;                       // sorted by class: the group has ended for this thread
+        if (!supp[j]) {
+          const float ovr = dev_iou(bx[ip], bx[ij]);
+          if (ge ? (ovr >= thr) : (ovr > thr)) supp[j] = 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int k = 0;
+    for (int p = 0; p < n; ++p)
+      if (!supp[p]) kept[base + k++] = order[p];
+    n2[f] = k;
+  }
+}
+
+// exclusive scan of per-frame counts by one thread (T is a few hundred at most) + the grand total
+__global__ void objcls_scan_kernel(const int* __restrict__ cnt, int T, int* __restrict__ off, int* __restrict__ total) {
+  if (blockIdx.x || threadIdx.x) return;
+  int acc = 0;
+  for (int f = 0; f < T; ++f) { off[f] = acc; acc += cnt[f]; }
+  off[T] = acc;
+  *total = acc;
+}
+
+// one workgroup per output row (grid = capacity; rows past the total exit): boxes, masked distribution, gathered
+// features, source row, and pred_scores / pred_labels = max / arg-max over columns 1.. (+2)  (lib/sttran.py:239-244)
+__global__ void __launch_bounds__(256)
+objcls_write_rows_kernel(const float* __restrict__ boxes, const float* __restrict__ dist, const float* __restrict__ feats,
+                         int ncol, int F, int T, const int* __restrict__ fstart, const int* __restrict__ ent_src,
+                         const uint64_t* __restrict__ ent_mask, const int* __restrict__ kept, const int* __restrict__ off2,
+                         float* __restrict__ o_boxes, float* __restrict__ o_dist, float* __restrict__ o_feats,
+                         float* __restrict__ o_score, int64_t* __restrict__ o_label, int* __restrict__ o_src) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  if (r >= off2[T]) return;
+  int lo = 0, hi = T;                                  // frame f with off2[f] <= r < off2[f+1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off2[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int f = lo;
+  const int64_t base = (int64_t)8 * fstart[f];
+  const int e = kept[base + (r - off2[f])];
+  const int src = ent_src[base + e];
+  const uint64_t m = ent_mask[base + e];
+  const float* drow = dist + (int64_t)src * ncol;
+  if (tid < ncol) o_dist[(int64_t)r * ncol + tid] = ((m >> tid) & 1) ? 0.f : drow[tid];
+  if (tid == 0) {
+    o_boxes[(int64_t)r * 5] = (float)f;
+    for (int c = 0; c < 4; ++c) o_boxes[(int64_t)r * 5 + 1 + c] = boxes[(int64_t)src * 5 + 1 + c];
+    float best;
+    const int bi = argmax_masked(drow, ncol, m, 1, &best);
+    o_score[r] = best;
+    o_label[r] = bi + 1;                                // column bi <-> class id bi + 1  (= arg-max over [:, 1:] + 2)
+    if (o_src) o_src[r] = src;
+  }
+  if (o_feats) {
+    const float* s = feats + (int64_t)src * F;
+    float* d = o_feats + (int64_t)r * F;
+    if ((F & 3) == 0) {
+      for (int i = tid * 4; i < F; i += 1024) *reinterpret_cast<f32x4*>(d + i) = *reinterpret_cast<const f32x4*>(s + i);
+    } else {
+      for (int i = tid; i < F; i += 256) d[i] = s[i];
+    }
+  }
+}
+
+// HUMAN_IDX (lib/sttran.py:247-254): per frame the box with the highest person score (column 0), 0 for a frame without
+// boxes -- and then, exactly like the reference's vectorised assignment, EVERY frame (empty ones included, whose index
+// is 0) overwrites label and score of its human row.
+__global__ void objcls_human_kernel(const float* __restrict__ o_dist, int ncol, int T, const int* __restrict__ off2,
+                                    int64_t* __restrict__ human) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= T) return;
+  int best_r = 0;
+  float best = 0.f;
+  for (int r = off2[f]; r < off2[f + 1]; ++r) {
+    const float v = o_dist[(int64_t)r * ncol];
+    if (r == off2[f] || v > best) { best = v; best_r = r; }
+  }
+  human[f] = best_r;
+}
+__global__ void objcls_override_kernel(const float* __restrict__ o_dist, int ncol, int T, const int64_t* __restrict__ human,
+                                       int total_rows_hint, const int* __restrict__ off2, float* __restrict__ o_score,
+                                       int64_t* __restrict__ o_label) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= T || off2[T] == 0) return;
+  const int64_t h = human[f];
+  o_label[h] = 1;
+  o_score[h] = o_dist[h * ncol];
+}
+
+// pairs (human of the frame, every box of the frame whose label is not 1), frame by frame (lib/sttran.py:256-266)
+__global__ void objcls_pair_count_kernel(const int64_t* __restrict__ o_label, int T, const int* __restrict__ off2,
+                                         int* __restrict__ np) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= T) return;
+  int c = 0;
+  for (int r = off2[f]; r < off2[f + 1]; ++r) c += o_label[r] != 1;
+  np[f] = c;
+}
+__global__ void objcls_pair_write_kernel(const int64_t* __restrict__ o_label, int T, const int* __restrict__ off2,
+                                         const int* __restrict__ poff, const int64_t* __restrict__ human,
+                                         int64_t* __restrict__ pair_idx, float* __restrict__ im_idx) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= T) return;
+  int p = poff[f];
+  for (int r = off2[f]; r < off2[f + 1]; ++r) {
+    if (o_label[r] == 1) continue;
+    pair_idx[2 * (int64_t)p] = human[f];
+    pair_idx[2 * (int64_t)p + 1] = r;
+    im_idx[p] = (float)f;
+    ++p;
+  }
+}
+
+// fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:16-118, one thread per (roi, channel, ph, pw)
+__device__ __forceinline__ float bilinear_interpolate(const float* __restrict__ data, int height, int width, float y, float x) {
+  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return 0.f;
+  if (y <= 0) y = 0;
+  if (x <= 0) x = 0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - (float)y_low, lx = x - (float)x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v1 = data[y_low * width + x_low], v2 = data[y_low * width + x_high];
+  const float v3 = data[y_high * width + x_low], v4 = data[y_high * width + x_high];
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+__global__ void __launch_bounds__(256)
+roi_align_kernel(int64_t nthreads, const float* __restrict__ bottom, float spatial_scale, int T, int channels, int height,
+                 int width, int pooled, int sampling_ratio, const float* __restrict__ rois, float* __restrict__ top) {
+  for (int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads; index += (int64_t)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % pooled);
+    const int ph = (int)((index / pooled) % pooled);
+    const int c = (int)((index / pooled / pooled) % channels);
+    const int64_t n = index / pooled / pooled / channels;
+    const float* roi = rois + n * 5;
+    int bi = (int)roi[0];
+    bi = min(max(bi, 0), T - 1);                         // (the reference would read out of bounds)
+    const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
+    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f), roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
+    const float bin_size_h = roi_height / (float)pooled, bin_size_w = roi_width / (float)pooled;
+    const float* data = bottom + ((int64_t)bi * channels + c) * height * width;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled);
+    const float count = (float)(grid_h * grid_w);
+    float out = 0.f;
+    for (int iy = 0; iy < grid_h; ++iy) {
+      const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+      for (int ix = 0; ix < grid_w; ++ix) {
+        const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+        out += bilinear_interpolate(data, height, width, y, x);
+      }
+    }
+    top[index] = out / count;
+  }
+}
+
+inline char* carve(char*& p, size_t bytes) {
+  char* r = p;
+  p += (bytes + 255) & ~size_t(255);
+  return r;
+}
+
+}  // namespace
+
+size_t objcls_scratch_bytes(int64_t B, int T) {
+  size_t n = 0;
+  auto add = [&](size_t b) { n += (b + 255) & ~size_t(255); };
+  add((size_t)(T + 2) * 4);                       // fstart
+  add((size_t)8 * B * 4); add((size_t)8 * B * 8); add((size_t)8 * B * 4);   // ent_src / ent_mask / ent_label
+  add((size_t)8 * B * 4);                         // kept
+  for (int i = 0; i < 5; ++i) add((size_t)(T + 2) * 4);   // n1, n2, off2, np, poff
+  add(64);                                        // totals + status
+  return n + 256;
+}
+
+// Everything up to the pair list.  Enqueues on `s`, then copies {rows, pairs, status} back and waits for it (the
+// reference synchronises dozens of times in this branch; the sizes of the outputs are data dependent).
+hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* dist, const float* feats,
+                                const int64_t* labels, int64_t B, int T, int ncol, int F, float thr, int ge, int64_t capacity,
+                                float* o_boxes, float* o_dist, float* o_feats, float* o_score, int64_t* o_label, int* o_src,
+                                int64_t* o_pair, float* o_im, int64_t* o_human, void* scratch, int32_t host_out[3]) {
+  if (ncol > kOcMaxCols || ncol < 2 || B <= 0 || T <= 0 || capacity < 1) return hipErrorInvalidValue;
+  char* p = reinterpret_cast<char*>(scratch);
+  int* fstart = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* ent_src = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
+  uint64_t* ent_mask = reinterpret_cast<uint64_t*>(carve(p, (size_t)8 * B * 8));
+  int* ent_label = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
+  int* kept = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
+  int* n1 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* n2 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* off2 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* np = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* poff = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
+  int* totals = reinterpret_cast<int*>(carve(p, 64));    // [0] rows, [1] pairs, [2] status
+  hipError_t e = hipMemsetAsync(totals, 0, 64, s);
+  if (e != hipSuccess) return e;
+  const int tb = 128, tg = (T + 1 + tb - 1) / tb;
+  hipLaunchKernelGGL(objcls_frame_ranges_kernel, dim3(tg), dim3(tb), 0, s, boxes, (int)B, T, fstart);
+  hipLaunchKernelGGL(objcls_expand_kernel, dim3(tg), dim3(tb), 0, s, dist, labels, ncol, T, fstart, ent_src, ent_mask, ent_label, n1);
+  hipLaunchKernelGGL(objcls_nms_kernel, dim3(T), dim3(256), 0, s, boxes, dist, ncol, fstart, ent_src, ent_mask, n1, thr, ge, kept,
+                     n2, totals + 2);
+  hipLaunchKernelGGL(objcls_scan_kernel, dim3(1), dim3(64), 0, s, n2, T, off2, totals);
+  const int64_t rows_cap = std::min<int64_t>(capacity, 8 * B);
+  hipLaunchKernelGGL(objcls_write_rows_kernel, dim3((unsigned)rows_cap), dim3(256), 0, s, boxes, dist, feats, ncol, F, T, fstart,
+                     ent_src, ent_mask, kept, off2, o_boxes, o_dist, o_feats, o_score, o_label, o_src);
+  hipLaunchKernelGGL(objcls_human_kernel, dim3(tg), dim3(tb), 0, s, o_dist, ncol, T, off2, o_human);
+  hipLaunchKernelGGL(objcls_override_kernel, dim3(tg), dim3(tb), 0, s, o_dist, ncol, T, o_human, 0, off2, o_score, o_label);
+  hipLaunchKernelGGL(objcls_pair_count_kernel, dim3(tg), dim3(tb), 0, s, o_label, T, off2, np);
+  hipLaunchKernelGGL(objcls_scan_kernel, dim3(1), dim3(64), 0, s, np, T, poff, totals + 1);
+  hipLaunchKernelGGL(objcls_pair_write_kernel, dim3(tg), dim3(tb), 0, s, o_label, T, off2, poff, o_human, o_pair, o_im);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipMemcpyAsync(host_out, totals, 12, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+
+hipError_t launch_roi_align(hipStream_t s, const float* fmaps, int T, int C, int H, int W, const float* rois, int64_t P,
+                            int pooled, float spatial_scale, int sampling_ratio, float* out) {
+  if (P <= 0) return hipSuccess;
+  const int64_t n = P * C * pooled * pooled;
+  const int64_t blocks = std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 64);
+  hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n, fmaps, spatial_scale, T, C, H, W, pooled,
+                     sampling_ratio, rois, out);
+  return hipGetLastError();
+}
+
+}  // namespace sttran

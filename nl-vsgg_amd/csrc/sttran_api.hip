@@ -1027,6 +1027,41 @@ int sttran_eval_recall(const SttranEvalInputs* in, uint8_t* flags, int32_t* stat
 
 int32_t sttran_eval_max_pairs(int32_t num_predicates) { return eval_max_pairs_per_frame(num_predicates); }
 
+int64_t sttran_objcls_scratch_bytes(int64_t num_boxes, int32_t num_frames) {
+  if (num_boxes < 0 || num_frames < 0) return 0;
+  return (int64_t)objcls_scratch_bytes(num_boxes, num_frames);
+}
+
+int sttran_objcls_select(const SttranObjclsSelect* a, int64_t* num_boxes_out, int64_t* num_pairs_out, void* stream) {
+  if (!a || a->struct_size != sizeof(SttranObjclsSelect) || !num_boxes_out || !num_pairs_out) return STTRAN_ERR_INVALID;
+  if (a->num_boxes <= 0 || a->num_frames <= 0) return STTRAN_ERR_EMPTY;
+  if (a->num_boxes > (1 << 26) || a->num_cols < 2 || a->num_cols > 64 || a->feat_dim < 0 || a->capacity < 8 * a->num_boxes)
+    return STTRAN_ERR_INVALID;
+  if (!a->boxes || !a->distribution || !a->pred_labels || !a->out_boxes || !a->out_distribution || !a->out_pred_scores ||
+      !a->out_pred_labels || !a->out_pair_idx || !a->out_im_idx || !a->out_human_idx || !a->scratch ||
+      (a->features != nullptr) != (a->out_features != nullptr) || (a->features && a->feat_dim <= 0) ||
+      a->scratch_bytes < (int64_t)objcls_scratch_bytes(a->num_boxes, a->num_frames))
+    return STTRAN_ERR_INVALID;
+  int32_t host[3] = {0, 0, 0};
+  hipError_t e = launch_objcls_select(reinterpret_cast<hipStream_t>(stream), a->boxes, a->distribution, a->features, a->pred_labels,
+                                      a->num_boxes, a->num_frames, a->num_cols, a->feat_dim, a->nms_threshold, a->nms_ge, a->capacity,
+                                      a->out_boxes, a->out_distribution, a->out_features, a->out_pred_scores, a->out_pred_labels,
+                                      a->out_source_row, a->out_pair_idx, a->out_im_idx, a->out_human_idx, a->scratch, host);
+  if (e != hipSuccess) return STTRAN_ERR_HIP;
+  if (host[2]) return STTRAN_ERR_LIMIT;            // a frame holds more than 1024 expanded boxes
+  *num_boxes_out = host[0];
+  *num_pairs_out = host[1];
+  return STTRAN_OK;
+}
+
+int sttran_roi_align(const float* fmaps, int32_t T, int32_t C, int32_t H, int32_t W, const float* rois, int64_t num_rois,
+                     int32_t pooled, float spatial_scale, int32_t sampling_ratio, float* out, void* stream) {
+  if (!fmaps || T <= 0 || C <= 0 || H <= 0 || W <= 0 || num_rois < 0 || pooled <= 0 || pooled > 64 || (num_rois > 0 && (!rois || !out)))
+    return STTRAN_ERR_INVALID;
+  return launch_roi_align(reinterpret_cast<hipStream_t>(stream), fmaps, T, C, H, W, rois, num_rois, pooled, spatial_scale,
+                          sampling_ratio, out) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
 // ---- kernel-level test hooks -------------------------------------------------------------------
 int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, const float* bias,
                       const float* residual, float* C, int64_t M, int64_t N, int64_t K, int32_t relu,

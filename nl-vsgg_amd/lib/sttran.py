@@ -45,10 +45,12 @@ class STTran:
                  obj_classes=None, enc_layer_num=None, dec_layer_num=None, transformer_mode=None, is_wks=True,
                  feat_dim=2048, motifs_path=None, conf=None):
         assert mode in ("sgdet", "sgcls", "predcls")          # lib/sttran.py:329
-        if mode == "sgcls" or (mode == "sgdet" and not is_wks):
-            raise NotImplementedError(
-                "only predcls and sgdet+is_wks are on the hot path (the other ObjectClassifier branches "
-                "need the detector's ROIAlign/NMS ops, lib/sttran.py:185-283)")
+        if mode == "sgcls":
+            raise NotImplementedError("sgcls is not on the hot path (NL-VSGG runs predcls and sgdet only)")
+        # sgdet WITHOUT weak supervision (lib/sttran.py:185-283): the ObjectClassifier selects boxes and
+        # pairs (clean_class, per-class NMS, ROIAlign of entry['fmaps']) with lib/object_classifier.py::sgdet_select
+        # and computes nothing learnt, so the relation path behind it is the predcls one fed with `pred_labels`.
+        self._select = mode == "sgdet" and not is_wks
         self.conf = conf
         self.mode = mode
         self.is_wks = is_wks
@@ -124,7 +126,8 @@ class STTran:
         if self._device is None:
             self._device = torch.cuda.current_device()
         cfg = nat.SttranConfig(
-            struct_size=C.sizeof(nat.SttranConfig), device=self._device, mode=nat.MODE[self.mode],
+            struct_size=C.sizeof(nat.SttranConfig), device=self._device,
+            mode=nat.MODE["predcls" if self._select else self.mode],
             enc_layers=self.enc_layer_num, dec_layers=self.dec_layer_num,
             attention_classes=int(self.attention_class_num), spatial_classes=int(self.spatial_class_num),
             contact_classes=int(self.contact_class_num), num_obj_classes=len(self.obj_classes),
@@ -241,9 +244,12 @@ class STTran:
         self._ensure_handle()
         lib, h = self._lib, self._handle
         f32, i64 = torch.float32, torch.int64
+        if self._select:
+            from .object_classifier import sgdet_select
+            entry = sgdet_select(entry)                      # lib/sttran.py:377 -> :185-283
         feats = self._dev(entry["features"], f32, "features")
         pair = self._dev(entry["pair_idx"], i64, "pair_idx")
-        labels = self._dev(entry["labels"], i64, "labels")
+        labels = self._dev(entry["pred_labels" if self._select else "labels"], i64, "labels")
         union = self._dev(entry["union_feat"], f32, "union_feat")
         masks = self._dev(entry["spatial_masks"], f32, "spatial_masks")
         P, B = int(pair.shape[0]), int(feats.shape[0])
@@ -282,7 +288,7 @@ class STTran:
         out.attention_distribution, out.spatial_distribution = att.data_ptr(), spa.data_ptr()
         out.contacting_distribution = con.data_ptr()
         keep = [feats, pair, labels, union, masks, im]
-        if self.mode != "predcls":
+        if self.mode != "predcls" and not self._select:
             boxes = self._dev(entry["boxes"], f32, "boxes")
             dist_in = self._dev(entry["distribution"], f32, "distribution")
             # the reference multiplies distribution [B, C-1] with obj_embed.weight [C-1, 200] (lib/sttran.py:174) and
@@ -306,8 +312,9 @@ class STTran:
         if self.check_indices:
             self.sync_check()
         # ---- the keys the reference writes (lib/sttran.py:91,182-184,404-409) ----
-        entry["pred_labels"] = entry["labels"]
-        if self.mode != "predcls":
+        if not self._select:
+            entry["pred_labels"] = entry["labels"]
+        if self.mode != "predcls" and not self._select:
             entry["distribution"] = dist_out
             entry["pred_scores"] = entry["scores"]
         entry["attention_distribution"] = att

@@ -325,3 +325,41 @@ def make_gt_annotation(seed: int, entry: dict) -> list:
             })
         gt.append(frame)
     return gt
+
+
+def make_detector_entry(seed: int, boxes_per_frame, feat_dim: int = 16, fmap_channels: int = 6, fmap_hw=(38, 50),
+                        image_wh=(800.0, 600.0)) -> dict:
+    """Raw detector output of one clip for the SGDet branch WITHOUT weak supervision (`lib/sttran.py:185-283`,
+    SURVEY 8f-2): many overlapping boxes per frame (clusters of jittered copies, so the per-class NMS has work to do),
+    a class distribution per box whose arg-max is also the detector's `pred_labels` (classes 5, 8 and 17 occur, so
+    `clean_class` duplicates boxes), box features and the backbone feature maps ROIAlign samples.
+    boxes_per_frame[t] may be 0 (a frame without detections)."""
+    counts = [int(c) for c in boxes_per_frame]
+    T, B = len(counts), int(sum(counts))
+    frame = np.repeat(np.arange(T), counts).astype(np.float32)
+    n_clusters = max(2, B // 3)
+    cxy = _u(seed, "det.cluster.xy", (n_clusters, 2), 0.0, 1.0) * np.asarray(image_wh, np.float32) * np.float32(0.7)
+    cwh = _u(seed, "det.cluster.wh", (n_clusters, 2), 40.0, 260.0)
+    which = Stream(seed, "det.cluster.of").randint(0, n_clusters - 1, B)
+    jit = _u(seed, "det.jitter", (B, 4), -14.0, 14.0)
+    x1y1 = cxy[which] + jit[:, :2]
+    x2y2 = x1y1 + np.maximum(cwh[which] + jit[:, 2:], np.float32(8.0))
+    x1y1 = np.maximum(x1y1, np.float32(0.0))
+    x2y2 = np.minimum(x2y2, np.asarray(image_wh, np.float32) - np.float32(1.0))
+    boxes = np.concatenate([frame[:, None], x1y1, x2y2], axis=1).astype(np.float32)
+    d = _u(seed, "det.distribution", (B, NUM_OBJ_CLASSES - 1), 0.0, 1.0)
+    # a dominant class per box: the cluster's class (so overlapping boxes compete inside one class), sometimes the
+    # person column, sometimes one of the classes clean_class re-labels (5, 8, 17 -> columns 4, 7, 16)
+    ccls = Stream(seed, "det.cluster.cls").randint(0, NUM_OBJ_CLASSES - 2, n_clusters)
+    special = np.asarray([0, 4, 7, 16, 4, 7])
+    pick = Stream(seed, "det.special").randint(0, 9, n_clusters)
+    ccls = np.where(pick < special.size, special[np.minimum(pick, special.size - 1)], ccls)
+    d[np.arange(B), ccls[which]] += _u(seed, "det.boost", (B,), 1.0, 2.0)
+    d = (d / d.sum(axis=1, keepdims=True)).astype(np.float32)
+    H, W = fmap_hw
+    return {
+        "boxes": boxes, "distribution": d, "pred_labels": (np.argmax(d, axis=1) + 1).astype(np.int64),
+        "features": _n(seed, "det.features", (B, feat_dim)),
+        "fmaps": _n(seed, "det.fmaps", (T, fmap_channels, H, W)),
+        "num_frames": T,
+    }
