@@ -3,7 +3,9 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<w>_FETCH_SIZE -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<w>_WRITE_SIZE -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_<w>_FETCH_SIZE gpurun_out/pmc_<w>_WRITE_SIZE > profiles/r1_pmc_traffic_<w>.json
+    python tools/pmc_traffic.py gpurun_out/pmc_<w>_FETCH_SIZE gpurun_out/pmc_<w>_WRITE_SIZE [commit] > profiles/rN_pmc_traffic_<w>.json
+(the profiled command is `bench.py --profile-only-batch`: warm-up + timed steps of one workload, nothing else; the
+optional third argument stamps the JSON with the commit the library was built from)
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of wide coalesced streaming reads (16 B/lane) -> doubled;
@@ -15,7 +17,7 @@ import sys
 
 import pandas as pd
 
-CLASSES = [("gemm", r"gemm_sk_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)|gemm_fixup_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)"),
+CLASSES = [("gemm", r"gemm_sk_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)|gemm_fixup(_vec)?_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)"),
            ("union_conv", r"EpiUnion"), ("attention", r"attention"), ("layernorm", r"layernorm"),
            ("mask_conv", r"mask_conv1_pool"), ("index", r"pair_prep|gather_rows|objcls")]
 
@@ -43,7 +45,8 @@ def main():
         out[name] = {"launches": int(n), "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,
                      "hbm_bytes_per_launch": (rd + wr) / n}
     json.dump({"note": "FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch (fix-up launches folded into "
-                       "their GEMM); all forwards of the profiled bench run", "classes": out}, sys.stdout, indent=1)
+                       "their GEMM); all forwards of the profiled bench run (bench.py --profile-only-batch)",
+               "commit": sys.argv[3] if len(sys.argv) > 3 else None, "classes": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
