@@ -906,7 +906,11 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   } else
   // ---- temporal decoder over 2-frame windows (lib/transformer.py:49-58,147-163) ----------------
   if (NT > 0 && c.dec_layers > 0) {
-    {
+    // window tokens G[r] = encoder row dec_src[r] (lib/transformer.py:153).  With two or more decoder layers the copy is
+    // never materialised: layer 0 projects q|k|v per PAIR straight from UNI and takes its residual through the same
+    // index; only a single-layer decoder (whose K/V and Q projections read token rows) builds G.
+    const bool need_g0 = c.dec_layers == 1;
+    if (need_g0) {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 8.0 * NT * D, "gather_rows_kernel", NT, D, 0);
       HIPCK(launch_gather_rows(s, UNI, LD, dec_src, G, LD, NT, D));
     }
@@ -949,6 +953,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       }
       EpiLinear eo = epi_plain(Y, LD, W(h, p + ".multihead2.out_proj.bias"));
       eo.res = G; eo.ldres = LD; eo.res_rowidx = rows;
+      if (i == 0 && !need_g0) { eo.res = UNI; eo.res_rowidx = dec_src; }      // residual = the window token's encoder row
       if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
       {
         ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D, "layernorm_kernel", MQ, D, 0);
