@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_e_bench_default_with_cpu.json")))
+    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("bench_default_with_cpu.json"))
+    d = json.load(open(os.path.join(ROOT, "profiles", lines[-1])))          # the newest round's default line
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -23,7 +24,12 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["host_cores"] >= c["cores"]
+    # round 2: per-kernel roofline rows and the second BASELINE workload ride in the same line
+    assert r["by_kernel"] and all(k in r["by_kernel"][0] for k in ("kernel", "launches_per_step", "gflop_per_step", "mean_us"))
+    w = d["workloads"]["64x36"]
+    assert w["value"] > 0 and 0.0 < w["roofline"]["frac"] < 1.0 and w["config"]["frames_per_clip"] == 64
+    assert d["one_clip_per_pass"]["value"] > 0
     assert abs(d["value"] - d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
