@@ -9,8 +9,10 @@ in HBM.  Workload of the line's `value` (default, BASELINE.json configs[1]): cli
 x 2048-d region features (P = 176 pairs per clip), `--clips-per-step` clips per pass (default 16).
 `--workload 64x36` selects configs[3]'s clip shape instead.  The default run ALSO measures the 64x36
 clip (one clip per step) in the same process and reports it under `workloads["64x36"]` -- north_star's
-scaling target is quoted on that workload -- and the one-clip-per-pass rate of the 16x12 clip (the
-reference's own batch size) under `one_clip_per_pass`.
+scaling target is quoted on that workload --, the DSG-DETR model of configs[4] under
+`workloads["dsgdetr_16x12"]`, a 256-clip sample of the configs[2] stand-in (Action-Genome-test-split-shaped clips,
+model + device evaluator) under `workloads["ag_split_shaped"]`, and the one-clip-per-pass rate of the 16x12 clip
+(the reference's own batch size) under `one_clip_per_pass`: every BASELINE config has a number in the line.
 
 With N > 1 every rank runs its own clips (whole-clip sharding, weak scaling: per-GPU work is fixed, so
 the aggregate grows ~N x unless host glue or the gather contends) and each step's predictions are
@@ -100,6 +102,51 @@ def cpu_baseline(T, N, sd, budget_s=24.0):
     return {"value": T / med, "unit": "frames/s", "cores": nthr, "host_cores": ncpu, "kind": "port",
             "sample": f"{nruns} forward(s) of one {T}x{N} clip, numpy/BLAS fp32 oracle, best of 8/32/{ncpu} BLAS "
                       f"threads (cores = the thread count of the best run), median {med:.3f} s/clip"}
+
+
+def ag_split_sample(device, n_clips):
+    """BASELINE configs[2] stand-in on a sample of the split: synthetic clips with the Action Genome test split's
+    frames-per-clip (tests/golden/ag_test_clip_lengths.json: the first `n_clips` of its 1 737 clips), 1..6 pairs per frame,
+    packed 16 per forward, predictions straight into the device evaluator (tools/ag_split_bench.py runs all of them)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ag_split_bench as ag
+    from nl_vsgg_amd.lib.evaluation_recall_hip import SceneGraphEvaluator_HIP
+    from nl_vsgg_amd.lib.sttran import unpack_predictions
+    with open(os.path.join(ROOT, "tests", "golden", "ag_test_clip_lengths.json")) as f:
+        lengths = json.load(f)["frames_per_clip"][:n_clips]
+    model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=ag.OBJ,
+                   enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(device)
+    model.eval(); model.check_indices = False
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()}, strict=False)
+    ev = SceneGraphEvaluator_HIP(mode="predcls", AG_object_classes=ag.OBJ, AG_all_predicates=ag.ATT + ag.SPA + ag.CON,
+                                 AG_attention_predicates=ag.ATT, AG_spatial_predicates=ag.SPA, AG_contacting_predicates=ag.CON,
+                                 iou_threshold=0.5)
+    ev.register_container()
+    rng = np.random.default_rng(2024)
+    gen = torch.Generator(device=device).manual_seed(2024)
+    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
+    chunk = [ag.make_clip(rng, gen, lengths[i], device) for i in order]
+    for _, gt in chunk:
+        gt.on(device)
+    warm = model(pack_clips([dict(c[0]) for c in chunk[:2]])); del warm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(0, len(chunk), 16):
+        group = chunk[i:i + 16]
+        preds = unpack_predictions(model(pack_clips([dict(c[0]) for c in group])))
+        for (e, gt), p in zip(group, preds):
+            p.update(pair_idx=e["pair_idx"], im_idx=e["im_idx"], boxes=e["boxes"], labels=e["labels"], scores=e["scores"])
+            ev.evaluate_scene_graph(gt, p)
+    ev.calculate_mean_recall()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = sum(c[0]["num_frames"] for c in chunk)
+    return {"value": frames / dt, "seconds": dt, "clips": len(chunk), "frames": frames,
+            "pairs": sum(int(c[0]["pair_idx"].shape[0]) for c in chunk),
+            "config": {"workload": "Action-Genome-test-split-shaped synthetic clips (frames per clip from ag_test_id.pkl, 1..6 pairs "
+                                   "per frame), STTran PredCls + device Recall@K evaluator, 16 clips per forward, features "
+                                   "resident in HBM; the real split's annotations / features are not shipped with the reference"},
+            "recall_with_constraint": {str(k): round(float(v), 4) for k, v in ev.summary()["recall"].items()}}
 
 
 class Env:
@@ -464,6 +511,31 @@ def main():
         if "roofline" in w:                              # keep the line readable: per-kernel rows, not per-shape
             w["roofline"].pop("by_shape", None)
         result["workloads"] = {"64x36": w}
+    # ---- the remaining BASELINE configs, driver-witnessed in the same line (single GPU, default run only) ----
+    if extras and world == 1 and args.model == "sttran" and args.workload == "16x12":
+        del model
+        torch.cuda.empty_cache()
+        try:                                             # configs[4]: DSG-DETR (lib/dsg_detr.py, sgdet branch) on the same kernels
+            from nl_vsgg_amd.lib.dsg_detr import STTran as DSGDETR
+            dsd = syn.make_dsg_detr_state_dict(7)
+            dm = DSGDETR(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17,
+                         obj_classes=CLASSES).to(device)
+            dm.eval(); dm.check_indices = False; dm.strict_inputs = True
+            dm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in dsd.items()}, strict=False)
+            w = run_workload(env, dm, "dsgdetr", "16x12", SHAPES["16x12"][2], max(5, min(args.steps, 20)), min(args.warmup, 3),
+                             roofline=not args.no_roofline)
+            w.pop("unit", None)
+            if "roofline" in w:
+                w["roofline"].pop("by_shape", None)
+            result["workloads"]["dsgdetr_16x12"] = w
+            del dm, dsd
+            torch.cuda.empty_cache()
+        except Exception as e:                           # an extra block must never cost the line
+            result["workloads"]["dsgdetr_16x12"] = {"error": repr(e)}
+        try:                                             # configs[2] stand-in: the loop of tools/test_STTran.py:75-92 on AG-shaped clips
+            result["workloads"]["ag_split_shaped"] = ag_split_sample(device, 256)
+        except Exception as e:
+            result["workloads"]["ag_split_shaped"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "sttran":
         result["cpu_baseline"] = cpu_baseline(T, N, sd)
     if rank == 0:

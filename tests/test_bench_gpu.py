@@ -67,6 +67,11 @@ def test_bench_default_line_shape():
     assert abs(gf / ms - r["achieved"]) < 1e-6 * r["achieved"]        # GFLOP per ms = TFLOP/s
     w = d["workloads"]["64x36"]
     assert w["value"] > 0 and w["roofline"]["frac"] > 0 and w["roofline"]["by_kernel"]
+    # BASELINE configs[4] (DSG-DETR) and the configs[2] stand-in ride in the same line
+    g = d["workloads"]["dsgdetr_16x12"]
+    assert "error" not in g and g["value"] > 0 and g["roofline"]["frac"] > 0
+    a = d["workloads"]["ag_split_shaped"]
+    assert "error" not in a and a["value"] > 0 and a["clips"] == 256 and a["frames"] > 5000
     # --profile-only-batch: nothing but warm-up + timed steps
     p = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
     assert "roofline" not in p and "workloads" not in p and "one_clip_per_pass" not in p and "cpu_baseline" not in p
