@@ -1,8 +1,8 @@
 // kernels_objcls.hip -- SURVEY 8f-2: the ObjectClassifier branch of SGDet WITHOUT weak supervision
 // (lib/sttran.py:185-283): clean_class (:52-85), per-(frame, class) greedy NMS at 0.6 (:203-237 with
 // fasterRCNN/lib/model/csrc/cuda/nms.cu:13-131), label / score / human selection (:239-254), pair enumeration
-// (:256-268) and ROIAlign of the union boxes on the detector's feature maps (:275 with
-// fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:16-118).
+// (:256-268) and ROIAlign of the union boxes on the detector's feature maps (:275; the op is
+// fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:65-118).
 //
 // Integer / index work plus a little float32 geometry: every float expression below is written with ONE rounding per
 // operation in the statement order of the reference sources (`#pragma clang fp contract(off)`: hipcc fuses a*b+c by
@@ -254,49 +254,65 @@ __global__ void objcls_pair_write_kernel(const int64_t* __restrict__ o_label, in
   }
 }
 
-// fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:16-118, one thread per (roi, channel, ph, pw)
-__device__ __forceinline__ float bilinear_interpolate(const float* __restrict__ data, int height, int width, float y, float x) {
-  if (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width) return 0.f;
-  if (y <= 0) y = 0;
-  if (x <= 0) x = 0;
-  int y_low = (int)y, x_low = (int)x, y_high, x_high;
-  if (y_low >= height - 1) { y_high = y_low = height - 1; y = (float)y_low; } else { y_high = y_low + 1; }
-  if (x_low >= width - 1) { x_high = x_low = width - 1; x = (float)x_low; } else { x_high = x_low + 1; }
-  const float ly = y - (float)y_low, lx = x - (float)x_low;
-  const float hy = 1.f - ly, hx = 1.f - lx;
-  const float v1 = data[y_low * width + x_low], v2 = data[y_low * width + x_high];
-  const float v3 = data[y_high * width + x_low], v4 = data[y_high * width + x_high];
-  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+// ---- ROIAlign forward (what fasterRCNN/lib/model/csrc/cuda/ROIAlign_cuda.cu:65-118 computes) -------------------------
+// A bilinear sample is separable: along each axis it is a pair of neighbouring cells with weights (1 - l, l), after the
+// reference's clamping rules for that axis (a coordinate in [-1, 0] snaps to 0, one at or past the last cell snaps onto
+// it, one outside [-1, size] makes the whole sample contribute 0).  The four corner weights are the products of the two
+// axes' weights -- the same float32 products, in the same order, as the reference's w1..w4.
+struct AxisTap {
+  int lo, hi;
+  float w_lo, w_hi;
+  bool inside;
+};
+__device__ __forceinline__ AxisTap axis_tap(float v, int size) {
+  AxisTap t;
+  t.inside = !(v < -1.0f || v > (float)size);
+  if (v <= 0) v = 0;
+  t.lo = (int)v;
+  if (t.lo >= size - 1) { t.hi = t.lo = size - 1; v = (float)t.lo; } else { t.hi = t.lo + 1; }
+  t.w_hi = v - (float)t.lo;
+  t.w_lo = 1.f - t.w_hi;
+  return t;
 }
+
+// grid = (rois, channel slices); a workgroup owns one roi and a slice of channels, its threads walk (channel, bin) with
+// the bin fastest.  The roi's geometry is derived once per thread, not once per output element.
 __global__ void __launch_bounds__(256)
-roi_align_kernel(int64_t nthreads, const float* __restrict__ bottom, float spatial_scale, int T, int channels, int height,
-                 int width, int pooled, int sampling_ratio, const float* __restrict__ rois, float* __restrict__ top) {
-  for (int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads; index += (int64_t)blockDim.x * gridDim.x) {
-    const int pw = (int)(index % pooled);
-    const int ph = (int)((index / pooled) % pooled);
-    const int c = (int)((index / pooled / pooled) % channels);
-    const int64_t n = index / pooled / pooled / channels;
-    const float* roi = rois + n * 5;
-    int bi = (int)roi[0];
-    bi = min(max(bi, 0), T - 1);                         // (the reference would read out of bounds)
-    const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
-    const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
-    const float roi_width = fmaxf(roi_end_w - roi_start_w, 1.f), roi_height = fmaxf(roi_end_h - roi_start_h, 1.f);
-    const float bin_size_h = roi_height / (float)pooled, bin_size_w = roi_width / (float)pooled;
-    const float* data = bottom + ((int64_t)bi * channels + c) * height * width;
-    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled);
-    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled);
-    const float count = (float)(grid_h * grid_w);
-    float out = 0.f;
-    for (int iy = 0; iy < grid_h; ++iy) {
-      const float y = roi_start_h + (float)ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
-      for (int ix = 0; ix < grid_w; ++ix) {
-        const float x = roi_start_w + (float)pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
-        out += bilinear_interpolate(data, height, width, y, x);
+roi_align_kernel(const float* __restrict__ fmaps, float spatial_scale, int T, int channels, int height, int width, int pooled,
+                 int sampling_ratio, const float* __restrict__ rois, float* __restrict__ out, int channels_per_block) {
+  const int64_t n = blockIdx.x;
+  const float* roi = rois + n * 5;
+  const int frame = min(max((int)roi[0], 0), T - 1);       // (the reference would read out of bounds)
+  // no rounding of the scaled corners; a malformed roi is forced to 1 x 1
+  const float x0 = roi[1] * spatial_scale, y0 = roi[2] * spatial_scale;
+  const float x1 = roi[3] * spatial_scale, y1 = roi[4] * spatial_scale;
+  const float roi_w = fmaxf(x1 - x0, 1.f), roi_h = fmaxf(y1 - y0, 1.f);
+  const float bin_h = roi_h / (float)pooled, bin_w = roi_w / (float)pooled;
+  // adaptive sampling grid: ceil(roi extent / pooled) samples per bin and axis
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_h / (float)pooled);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_w / (float)pooled);
+  const float inv_count = (float)(gh * gw);
+  const int bins = pooled * pooled;
+  const int c_begin = blockIdx.y * channels_per_block, c_end = min(channels, c_begin + channels_per_block);
+  for (int idx = threadIdx.x; idx < (c_end - c_begin) * bins; idx += 256) {
+    const int c = c_begin + idx / bins, bin = idx % bins;
+    const int ph = bin / pooled, pw = bin - ph * pooled;
+    const float* map = fmaps + ((int64_t)frame * channels + c) * height * width;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      const AxisTap ty = axis_tap(y0 + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh, height);
+      const float* row_lo = map + ty.lo * width;
+      const float* row_hi = map + ty.hi * width;
+      for (int ix = 0; ix < gw; ++ix) {
+        const AxisTap tx = axis_tap(x0 + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw, width);
+        float v = 0.f;
+        if (ty.inside && tx.inside)
+          v = (ty.w_lo * tx.w_lo) * row_lo[tx.lo] + (ty.w_lo * tx.w_hi) * row_lo[tx.hi] + (ty.w_hi * tx.w_lo) * row_hi[tx.lo] +
+              (ty.w_hi * tx.w_hi) * row_hi[tx.hi];
+        acc += v;
       }
     }
-    top[index] = out / count;
+    out[(n * channels + c) * bins + bin] = acc / inv_count;
   }
 }
 
@@ -364,10 +380,13 @@ hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* 
 hipError_t launch_roi_align(hipStream_t s, const float* fmaps, int T, int C, int H, int W, const float* rois, int64_t P,
                             int pooled, float spatial_scale, int sampling_ratio, float* out) {
   if (P <= 0) return hipSuccess;
-  const int64_t n = P * C * pooled * pooled;
-  const int64_t blocks = std::min<int64_t>((n + 255) / 256, (int64_t)num_cus() * 64);
-  hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n, fmaps, spatial_scale, T, C, H, W, pooled,
-                     sampling_ratio, rois, out);
+  if (P > 0x7fffffff) return hipErrorInvalidValue;
+  // enough workgroups to fill the chip even for a handful of rois; >= 32 channels (x 49 bins) per workgroup
+  const int want = std::max(1, (int)((int64_t)num_cus() * 8 / P));
+  const int slices = std::min((C + 31) / 32, want);
+  const int cpb = (C + slices - 1) / slices;
+  hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)P, (unsigned)((C + cpb - 1) / cpb)), dim3(256), 0, s, fmaps, spatial_scale, T, C,
+                     H, W, pooled, sampling_ratio, rois, out, cpb);
   return hipGetLastError();
 }
 
