@@ -79,15 +79,16 @@ __global__ void objcls_expand_kernel(const float* __restrict__ dist, const int64
   n1[f] = n;
 }
 
-// fasterRCNN/lib/model/csrc/cuda/nms.cu:13-21
-__device__ __forceinline__ float dev_iou(const float* a, const float* b) {
-  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-  const float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
-  const float interS = width * height;
-  const float Sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
-  const float Sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
-  return interS / (Sa + Sb - interS);
+// IoU of two boxes whose extents count both border pixels (width = x2 - x1 + 1): the measure the reference's nms op
+// thresholds (fasterRCNN/lib/model/csrc/cuda/nms.cu:13-21).  float32, one rounding per operation, union = area(p) +
+// area(q) - overlap in that order -- the value decides keep / drop, so the operation order is part of the contract.
+__device__ __forceinline__ float box_iou_inclusive(const float* p, const float* q) {
+  const float ox = fmaxf(fminf(p[2], q[2]) - fmaxf(p[0], q[0]) + 1.f, 0.f);     // overlap extent in x
+  const float oy = fmaxf(fminf(p[3], q[3]) - fmaxf(p[1], q[1]) + 1.f, 0.f);     // ... and in y
+  const float overlap = ox * oy;
+  const float area_p = (p[2] - p[0] + 1.f) * (p[3] - p[1] + 1.f);
+  const float area_q = (q[2] - q[0] + 1.f) * (q[3] - q[1] + 1.f);
+  return overlap / (area_p + area_q - overlap);
 }
 
 // One workgroup per frame: class of every expanded box = arg-max of its (masked) distribution; order by (class
@@ -139,7 +140,7 @@ objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dis
         const int ij = order[j];
         if (cls[ij] != cp) break;                       // sorted by class: the group has ended for this thread
         if (!supp[j]) {
-          const float ovr = dev_iou(bx[ip], bx[ij]);
+          const float ovr = box_iou_inclusive(bx[ip], bx[ij]);
           if (ge ? (ovr >= thr) : (ovr > thr)) supp[j] = 1;
         }
       }
