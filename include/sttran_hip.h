@@ -275,6 +275,13 @@ int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* W, c
 int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
                              const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                              int32_t relu, int32_t tile_cfg, void* stream);
+/* EXPERIMENT (not on the product's default path): the same GEMM with fp32 EMULATED on the bf16 matrix pipe -- operands
+ * split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+ * (csrc/gemm_bf16x3.h).  W [N,K] fp32 (row stride ldw) is split into planes inside the call (untimed by the caller's
+ * events only if it warms up first: the planes are cached per W pointer). */
+int sttran_debug_gemm_x3(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
+                         const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                         int32_t relu, void* stream);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
 int sttran_debug_mfma_peak(int32_t iters, double* tflops);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */

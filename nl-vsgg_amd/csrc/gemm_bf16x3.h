@@ -1,0 +1,236 @@
+// gemm_bf16x3.h -- fp32 GEMM emulated on the bf16 matrix pipe (EXPERIMENT: opt-in, not the product's default path).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )
+//
+// Every fp32 operand x is split into three bf16 planes x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2): 3 x 8 mantissa bits = the 24 of fp32), and a product a.b is evaluated as the six cross terms
+// a1b1 + a1b2 + a2b1 + a1b3 + a3b1 + a2b2 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  A bf16 x bf16 product is
+// exact in fp32, and the three dropped terms (a2b3, a3b2, a3b3) are below 2^-24 |a||b|: the result carries fp32-level
+// error, at 16 / 6 = 2.7x the rate of v_mfma_f32_32x32x2_f32 (ceiling 419 TFLOP/s-equivalent on MI355X).
+//
+// Weights arrive already split (three bf16 planes [3][N][ldp], zero-padded to a multiple of 32 columns, made once at
+// load time); activations stay fp32 in HBM and are split by the A loader on their way into LDS (v_cvt_pk_bf16_f32 +
+// shift + subtract: ~5 VALU operations per element, issued under the MFMAs).
+//
+// Layout: per LDS stage three planes of [BM + BN rows][32 k] bf16 (64 bytes per row, unpadded); the ds_read_b128
+// fragment reads (lane = row & 31, k half = lane >> 5: 8 consecutive k per lane, what the 32x32x16 MFMA wants) are kept
+// conflict-free by XOR-ing the 16-byte chunk index with (row >> 2) & 3.  One fragment read feeds three MFMAs (each
+// plane of A meets two or three planes of B), i.e. half the LDS traffic per MFMA of a plain bf16 GEMM.
+// Swapped operand ports and the 16-byte vector epilogue, the hybrid data-parallel + stream-K schedule and the fix-up
+// launch are those of gemm_f32_mfma.h (same accumulator layout, same parking format).
+#pragma once
+#include "gemm_f32_mfma.h"
+
+namespace sttran {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct X3Weights {
+  const __bf16* planes;     // [3][rows][ldp]
+  int64_t ldp;              // row stride in elements (multiple of 32)
+  int64_t plane_stride;     // rows * ldp
+};
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct X3Tile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int NT = WM * WN * 64;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int ROWS = BM + BN;
+  static constexpr int AV = BM * 8 / NT;                    // float4 loads per thread per K-step (A, fp32)
+  static constexpr int BV = 3 * BN * 4 / NT;                // 16-byte loads per thread per K-step (B, three bf16 planes)
+  static constexpr int STAGE_BYTES = 3 * ROWS * 64;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int GROUP_N = 8;
+  static_assert((BM * 8) % NT == 0 && (3 * BN * 4) % NT == 0, "staging must divide evenly");
+};
+
+// x -> (hi, mid, lo) bf16 planes, four elements at a time
+__device__ __forceinline__ void split3(const f32x4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = (__bf16)v[i];
+    const float r1 = v[i] - (float)h[i];
+    m[i] = (__bf16)r1;
+    l[i] = (__bf16)(r1 - (float)m[i]);
+  }
+}
+
+// One-off: split a [rows, cols] fp32 matrix (row stride ld) into three zero-padded bf16 planes [3][rows][ldp].
+__global__ void __launch_bounds__(256)
+split_planes_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols, __bf16* __restrict__ planes, int64_t ldp) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < (int)ldp; c += 256) {
+    const float v = c < cols ? src[(int64_t)r * ld + c] : 0.f;
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    const int64_t o = (int64_t)r * ldp + c, ps = (int64_t)rows * ldp;
+    planes[o] = h; planes[ps + o] = m; planes[2 * ps + o] = l;
+  }
+}
+
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT)
+gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg, int g_sk,
+               int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV, ROWS = T::ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int fr = lane & 31, fh = lane >> 5;
+  // fragment read offsets (bytes, inside one plane of one stage) of k16 group g: chunk = (2 g + fh) ^ ((row >> 2) & 3)
+  const int fswz = (fr >> 2) & 3;
+  int fa_off[2], fb_off[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int ch = ((2 * g + fh) ^ fswz) * 16;
+    fa_off[g] = (wm * (BM / T::WM) + fr) * 64 + ch;
+    fb_off[g] = (BM + wn * (BN / T::WN) + fr) * 64 + ch;
+  }
+  // staging roles.  A: float4 (4 k) of row (tid >> 3) + i * NT/8 -> 8 bytes of each plane.  B: 16-byte chunk.
+  const int a_c = (tid & 7) >> 1, a_half = tid & 1;
+
+  const int G = gridDim.x;
+  const int blk = xcd_remap(blockIdx.x, G);
+  const int tiles_dp = dp_per_wg * G;
+  const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
+
+  int dp_done = 0;
+  for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
+    int tile, ks0, ks1;
+    const bool dp = dp_done < dp_per_wg;
+    if (dp) { tile = dp_done * G + blk; ks0 = 0; ks1 = ksteps; ++dp_done; }
+    else {
+      const int t = it / ksteps;
+      tile = tiles_dp + t;
+      ks0 = it - t * ksteps;
+      ks1 = min(ksteps, ks0 + (rg.end - it));
+    }
+    const int nsteps = ks1 - ks0;
+    int tile_m, tile_n;
+    tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const float* pa[AV];
+    int wa[AV];                                     // LDS byte offset of the 8-byte piece inside a plane
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int row = (tid >> 3) + i * (NT >> 3);
+      const int g = m0 + row;
+      pa[i] = A.ptr + (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + ks0 * kBK + (tid & 7) * 4;
+      wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
+    }
+    const __bf16* pb[BV];
+    int wb[BV];                                     // LDS byte offset inside the stage (plane included)
+#pragma unroll
+    for (int j = 0; j < BV; ++j) {
+      const int idx = tid + j * NT;
+      const int plane = idx / (BN * 4), rem = idx - plane * (BN * 4), row = rem >> 2, c = rem & 3;
+      const int g = n0 + row;
+      pb[j] = B.planes + plane * B.plane_stride + (int64_t)(g < N ? g : 0) * B.ldp + ks0 * kBK + c * 8;
+      wb[j] = (plane * ROWS + BM + row) * 64 + ((c ^ ((row >> 2) & 3)) * 16);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[AV];
+    bf16x8 rb[BV];
+    auto load_step = [&](int step) {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + step * kBK);
+#pragma unroll
+      for (int j = 0; j < BV; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(pb[j] + step * kBK);
+    };
+    auto store_step = [&](unsigned char* stage) {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        bf16x4 h, m, l;
+        split3(ra[i], h, m, l);
+        *reinterpret_cast<bf16x4*>(stage + wa[i]) = h;
+        *reinterpret_cast<bf16x4*>(stage + ROWS * 64 + wa[i]) = m;
+        *reinterpret_cast<bf16x4*>(stage + 2 * ROWS * 64 + wa[i]) = l;
+      }
+#pragma unroll
+      for (int j = 0; j < BV; ++j) *reinterpret_cast<bf16x8*>(stage + wb[j]) = rb[j];
+    };
+    // one k16 group: 3 planes x (TM + TN) fragment reads, 6 x TM x TN MFMAs (small terms first)
+    auto compute_group = [&](const unsigned char* stage, int g) {
+      bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(stage + p * ROWS * 64 + fa_off[g] + i * 32 * 64);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(stage + p * ROWS * 64 + fb_off[g] + j * 32 * 64);
+      }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (a plane, b plane) of the six terms
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)      // swapped ports: the weight fragment feeds the "A" port (EpiTraits)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB[t]][j], fa[PA[t]][i], acc[i][j], 0, 0, 0);
+    };
+
+    load_step(0);
+    store_step(smem_raw);
+    __syncthreads();
+    for (int t = 0; t < nsteps; ++t) {
+      const unsigned char* cur = smem_raw + (t & 1) * T::STAGE_BYTES;
+      unsigned char* nxt = smem_raw + ((t + 1) & 1) * T::STAGE_BYTES;
+      load_step(t + 1 < nsteps ? t + 1 : 0);          // the step past the range re-reads step 0 into the idle stage
+      compute_group(cur, 0);
+      compute_group(cur, 1);
+      store_step(nxt);
+      __syncthreads();
+    }
+
+    // C/D layout with swapped ports: row m = lane & 31 of block i, cols n = 8 q + 4 (lane >> 5) + {0..3} of block j
+    const int row = m0 + wm * (BM / T::WM) + fr;
+    const int cbase = n0 + wn * (BN / T::WN) + 4 * fh;
+    if (nsteps == ksteps) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = row + i * 32;
+        if (r < M) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int col = cbase + j * 32 + 8 * q;
+              const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              if (col + 3 < N) epi.vec(r, col, v);
+              else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  if (col + c < N) epi(r, col + c, v[c]);
+              }
+            }
+        }
+      }
+    } else {
+      f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            sp[((i * TN + j) * 4 + q) * NT] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    }
+    if (!dp) it += nsteps;
+    __syncthreads();
+  }
+}
+
+}  // namespace sttran

@@ -1105,6 +1105,36 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+int sttran_debug_gemm_x3(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+                         const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                         int32_t relu, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < pad32(K) || ldw < K || (lda & 3)) return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static float* slab = nullptr;
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess)) return STTRAN_ERR_HIP;
+  // weight planes, cached for the last W pointer / shape (test hook: one matrix at a time)
+  static void* planes = nullptr;
+  static size_t planes_bytes = 0;
+  static const float* cached_w = nullptr;
+  static int64_t cached_n = 0, cached_k = 0;
+  const int64_t ldp = pad32(K);
+  const size_t need = (size_t)3 * N * ldp * 2 + 256;
+  if (need > planes_bytes) {
+    if (planes) hipFree(planes);
+    if (hipMalloc(&planes, need) != hipSuccess) { planes = nullptr; planes_bytes = 0; return STTRAN_ERR_HIP; }
+    planes_bytes = need;
+    cached_w = nullptr;
+  }
+  if (cached_w != Wt || cached_n != N || cached_k != K) {
+    if (split_planes(s, Wt, ldw, (int)N, (int)K, planes, ldp) != hipSuccess) return STTRAN_ERR_HIP;
+    cached_w = Wt; cached_n = N; cached_k = K;
+  }
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  hipError_t err = gemm_linear_x3(s, GemmOperand{A, lda, a_rowidx}, planes, ldp, (int)M, (int)N, (int)K, e, slab);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
 int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
   if (iters <= 0 || !tflops) return STTRAN_ERR_INVALID;
   float* out = nullptr;

@@ -243,3 +243,27 @@ def test_gemm_stream_k_reuse_stress(lib, M, N, K, tile):
         err = (outs[0].double() - ref).abs().max().item()
         assert err < tol * max(1.0, ref.abs().max().item() / (K ** 0.5)), (it, err)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), it
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (2816, 1936, 1936), (1, 4, 32), (257, 130, 100), (5280, 2048, 1936)])
+def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
+    """the experimental bf16x3 engine (three bf16 planes per operand, six cross products, fp32 accumulate) must be as
+    close to an fp64 reference as the exact-fp32 MFMA engine is -- it is an emulation of fp32, not a reduced precision"""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    Kp = (K + 31) // 32 * 32
+    A = torch.randn(M + 1, Kp, device="cuda", generator=g) * 2
+    A[:, K:] = 0                                              # the product keeps the pad columns zero
+    W = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    C3 = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.sttran_debug_gemm_x3(_p(A), Kp, None, _p(W), K, _p(b), _p(res), _p(C3), M, N, K, 1, None) == 0
+    Wp = torch.zeros(N, Kp, device="cuda"); Wp[:, :K] = W
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(Wp), Kp, _p(b), _p(res), _p(C1), M, N, K, 1, 0, None) == 0
+    torch.cuda.synchronize()
+    ref = _ref(A[:M, :K], W, b, res, relu=1)
+    e3 = (C3.double() - ref).abs().max().item()
+    e1 = (C1.double() - ref).abs().max().item()
+    assert torch.isfinite(C3).all()
+    assert e3 <= 2.0 * e1 + 1e-6, (e3, e1)

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--pipes", default="0", help="main-loop variants (library built with EXTRA=-DSTTRAN_GEMM_EXPERIMENT)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--residual", action="store_true", help="add a residual [M,N] in the epilogue (out-proj / FFN2 form)")
+    ap.add_argument("--x3", action="store_true", help="also time the bf16x3 fp32-emulation engine (experiment)")
     ap.add_argument("--zeros", action="store_true", help="zero operands: separates clock (power) limits from schedule limits")
     ap.add_argument("--cold", action="store_true",
                     help="overwrite a 768 MB buffer before every timed launch (operands come from HBM, not from the "
@@ -92,6 +93,24 @@ def main():
                 rows.append((tile, split, us, tf))
                 if tile and (best is None or us < best[2]):
                     best = (tile, split, us, tf)
+        if a.x3:
+            Wd = W[:, :K].contiguous() if Kp != K else W
+            for _ in range(3):
+                lib.sttran_debug_gemm_x3(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                lib.sttran_debug_gemm_x3(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.iters
+            ref = (A[:M, :K].double() @ Wd.double().T + b.double() + (R.double() if a.residual else 0))
+            err3 = (Cc.double() - ref).abs().max().item()
+            lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, 1, None)
+            torch.cuda.synchronize()
+            err1 = (Cc.double() - ref).abs().max().item()
+            print(f"     bf16x3: {us:9.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF-equivalent   max|err| vs fp64: x3 {err3:.3e}  fp32-MFMA {err1:.3e}")
         auto = rows[0]
         print(f"{name:10s} M={M:6d} N={N:6d} K={K:5d}  auto {auto[2]:9.1f} us {auto[3]:6.1f} TF | best "
               f"{TILES[best[0]]}/p{best[1]} {best[2]:9.1f} us {best[3]:6.1f} TF")
