@@ -142,29 +142,27 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 ra[AV];
-    bf16x8 rb[BV];
-    auto load_step = [&](int step) {
+    // Two K-steps of global prefetch: the raw loads of step t+2 are issued at the top of step t into one of two register
+    // sets; the set loaded one step earlier (step t+1) is split into planes and written to the other LDS stage under
+    // the MFMAs of step t.
+    f32x4 ra[2][AV];
+    bf16x8 rb[2][BV];
+    auto load_step = [&](int set, int step) {
+      const int st = step < nsteps ? step : 0;            // steps past the range re-read step 0 (never consumed)
 #pragma unroll
-      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + step * kBK);
+      for (int i = 0; i < AV; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + st * kBK);
 #pragma unroll
-      for (int j = 0; j < BV; ++j) rb[j] = *reinterpret_cast<const bf16x8*>(pb[j] + step * kBK);
+      for (int j = 0; j < BV; ++j) rb[set][j] = *reinterpret_cast<const bf16x8*>(pb[j] + st * kBK);
     };
-    auto store_step = [&](unsigned char* stage) {
-#pragma unroll
-      for (int i = 0; i < AV; ++i) {
-        bf16x4 h, m, l;
-        split3(ra[i], h, m, l);
-        *reinterpret_cast<bf16x4*>(stage + wa[i]) = h;
-        *reinterpret_cast<bf16x4*>(stage + ROWS * 64 + wa[i]) = m;
-        *reinterpret_cast<bf16x4*>(stage + 2 * ROWS * 64 + wa[i]) = l;
-      }
-#pragma unroll
-      for (int j = 0; j < BV; ++j) *reinterpret_cast<bf16x8*>(stage + wb[j]) = rb[j];
+    auto store_a = [&](int set, int i, unsigned char* stage) {
+      bf16x4 h, m, l;
+      split3(ra[set][i], h, m, l);
+      *reinterpret_cast<bf16x4*>(stage + wa[i]) = h;
+      *reinterpret_cast<bf16x4*>(stage + ROWS * 64 + wa[i]) = m;
+      *reinterpret_cast<bf16x4*>(stage + 2 * ROWS * 64 + wa[i]) = l;
     };
-    // one k16 group: 3 planes x (TM + TN) fragment reads, 6 x TM x TN MFMAs (small terms first)
-    auto compute_group = [&](const unsigned char* stage, int g) {
-      bf16x8 fa[3][TM], fb[3][TN];
+    auto store_b = [&](int set, int j, unsigned char* stage) { *reinterpret_cast<bf16x8*>(stage + wb[j]) = rb[set][j]; };
+    auto read_frags = [&](const unsigned char* stage, int g, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -172,27 +170,51 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(stage + p * ROWS * 64 + fb_off[g] + j * 32 * 64);
       }
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (a plane, b plane) of the six terms
+    };
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // (a plane, b plane) of the six terms, small first
+    // 6 x TM x TN MFMAs of one k16 group; `extra(n)` is called after the n-th MFMA (staging work rides in the gaps)
+    auto mma_group = [&](const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN], auto&& extra) {
+      int n = 0;
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)      // swapped ports: the weight fragment feeds the "A" port (EpiTraits)
+          for (int j = 0; j < TN; ++j) {     // swapped ports: the weight fragment feeds the "A" port (EpiTraits)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB[t]][j], fa[PA[t]][i], acc[i][j], 0, 0, 0);
+            extra(n++);
+          }
     };
 
-    load_step(0);
-    store_step(smem_raw);
+    load_step(0, 0);
+#pragma unroll
+    for (int i = 0; i < AV; ++i) store_a(0, i, smem_raw);
+#pragma unroll
+    for (int j = 0; j < BV; ++j) store_b(0, j, smem_raw);
+    load_step(1, 1);
     __syncthreads();
-    for (int t = 0; t < nsteps; ++t) {
+    bf16x8 fa[3][TM], fb[3][TN];
+    auto one_step = [&](int t, int set_store, int set_load) {
       const unsigned char* cur = smem_raw + (t & 1) * T::STAGE_BYTES;
       unsigned char* nxt = smem_raw + ((t + 1) & 1) * T::STAGE_BYTES;
-      load_step(t + 1 < nsteps ? t + 1 : 0);          // the step past the range re-reads step 0 into the idle stage
-      compute_group(cur, 0);
-      compute_group(cur, 1);
-      store_step(nxt);
+      load_step(set_load, t + 2);            // the set written to LDS during the previous step receives step t+2
+      read_frags(cur, 0, fa, fb);
+      // group 0: the split + LDS writes of step t+1 (raw data loaded during step t-1) ride under the MFMAs
+      mma_group(fa, fb, [&](int n) {
+        if (n < AV) store_a(set_store, n, nxt);
+        else if (n - AV < BV) store_b(set_store, n - AV, nxt);
+      });
+      read_frags(cur, 1, fa, fb);
+      mma_group(fa, fb, [&](int) {});
       __syncthreads();
+    };
+    {
+      int t = 0;
+      for (; t + 1 < nsteps; t += 2) {
+        one_step(t, 1, 0);
+        one_step(t + 1, 0, 1);
+      }
+      if (t < nsteps) one_step(t, 1, 0);
     }
 
     // C/D layout with swapped ports: row m = lane & 31 of block i, cols n = 8 q + 4 (lane >> 5) + {0..3} of block j
