@@ -450,6 +450,9 @@ def main():
                          "enqueues on the caller's stream, so it is capturable once the layout is cached")
     ap.add_argument("--pcie", action="store_true",
                     help="also report the rate when every step first copies its inputs from pinned host memory")
+    ap.add_argument("--gemm-engine", default="fp32", choices=["fp32", "bf16x3"],
+                    help="bf16x3 = EXPERIMENT: the nn.Linear GEMMs with fp32 emulated on the bf16 matrix pipe (three bf16 planes per "
+                         "operand, six cross products, fp32 accumulate); the default line reports it as an extra block only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
@@ -481,6 +484,7 @@ def main():
     model.eval()
     model.check_indices = False      # enqueue-only: no per-call synchronisation inside the timed region
     model.strict_inputs = True       # a hidden per-step copy of the inputs would be timed as compute
+    model.gemm_engine = args.gemm_engine
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
 
     extras = not args.no_extra_workloads
@@ -492,7 +496,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.gemm_engine == "fp32" else "f32 emulated as 3 x bf16 planes (bf16 MFMA, fp32 accumulate) in the "
+                                                         "nn.Linear GEMMs; f32 elsewhere",
+        "data": "synthetic",
         "config": main_res["config"],
     }
     if world > 1:
@@ -511,6 +517,26 @@ def main():
         if "roofline" in w:                              # keep the line readable: per-kernel rows, not per-shape
             w["roofline"].pop("by_shape", None)
         result["workloads"] = {"64x36": w}
+    # ---- EXPERIMENT block: the same workload with the bf16x3 GEMM engine, and how far its outputs are from the exact
+    #      engine's on the same batch (never `value`)
+    if extras and world == 1 and args.model == "sttran" and args.workload == "16x12" and args.gemm_engine == "fp32":
+        try:
+            gen = torch.Generator(device=device).manual_seed(99)
+            probe = pack_clips([device_clip(T, N, gen, device) for _ in range(4)])
+            ref = {k: v.clone() for k, v in model(dict(probe)).items() if k.endswith("_distribution")}
+            model.gemm_engine = "bf16x3"
+            got = model(dict(probe))
+            diff = max(float((got[k] - ref[k]).abs().max()) for k in ref)
+            w = run_workload(env, model, args.model, "16x12", cps, max(5, min(args.steps, 20)), min(args.warmup, 3), roofline=False)
+            w.pop("unit", None)
+            w["max_abs_diff_vs_fp32_engine"] = diff
+            w["note"] = ("EXPERIMENT, opt-in (model.gemm_engine = 'bf16x3'): nn.Linear GEMMs with M >= 512 on "
+                         "v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 planes, six cross products, fp32 "
+                         "accumulate; error vs fp64 no larger than the exact fp32-MFMA engine's (tests/test_kernels_gpu.py)")
+            result["workloads"]["16x12_bf16x3"] = w
+        except Exception as e:
+            result["workloads"]["16x12_bf16x3"] = {"error": repr(e)}
+        model.gemm_engine = "fp32"
     # ---- the remaining BASELINE configs, driver-witnessed in the same line (single GPU, default run only) ----
     if extras and world == 1 and args.model == "sttran" and args.workload == "16x12":
         del model

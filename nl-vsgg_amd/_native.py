@@ -90,6 +90,7 @@ SYMBOLS = [
     ("sttran_finalize_weights", C.c_int, [C.c_void_p]),
     ("sttran_missing_keys", C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     ("sttran_reserve", C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    ("sttran_set_gemm_engine", C.c_int, [C.c_void_p, C.c_int32]),
     ("sttran_forward", C.c_int, [C.c_void_p, C.POINTER(SttranInputs), C.POINTER(SttranOutputs), C.c_void_p]),
     ("sttran_sync_check", C.c_int, [C.c_void_p, C.c_void_p]),
     ("sttran_destroy", None, [C.c_void_p]),

@@ -55,8 +55,9 @@ hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks);
 
 // bf16x3 fp32 emulation (gemm_bf16x3.h; experiment): weight planes [3][rows][ldp] bf16 made by split_planes
 hipError_t split_planes(hipStream_t s, const float* W, int64_t ld, int rows, int cols, void* planes, int64_t ldp);
-hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int M, int N, int K,
-                          const EpiLinear& epi, float* slab);
+// planes points at the first needed weight row of plane 0; plane_stride = elements between planes (rows_total * ldp)
+hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int64_t plane_stride, int M,
+                          int N, int K, const EpiLinear& epi, float* slab);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // pair_idx/labels (int64) -> int32 gather indices + the two class-embedding column blocks of x

@@ -40,11 +40,11 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 // planes: [3][N][ldp] bf16 of the weight matrix (split_planes); A fp32 with the padded-operand contract (readable and
 // finite up to ceil32(K) columns per row)
-hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int M, int N, int K,
-                          const EpiLinear& epi, float* slab) {
+hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int64_t plane_stride, int M, int N,
+                          int K, const EpiLinear& epi, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
   if ((ldp & 31) || ldp < ((K + 31) & ~31) || !al16(planes) || !al16(A.ptr) || (A.ld & 3)) return hipErrorInvalidValue;
-  X3Weights B{reinterpret_cast<const __bf16*>(planes), ldp, (int64_t)N * ldp};
+  X3Weights B{reinterpret_cast<const __bf16*>(planes), ldp, plane_stride};
   using T = X3Tile<256, 128, 4, 2>;
   const bool vec = (N & 3) == 0 && al16(epi.C) && (epi.ldc & 3) == 0 && al16(epi.bias) && al16(epi.rowbias) && (epi.rb_ld & 3) == 0 &&
                    (epi.rb_cols & 3) == 0 && al16(epi.scale) && al16(epi.shift) && al16(epi.res) && (epi.ldres & 3) == 0;

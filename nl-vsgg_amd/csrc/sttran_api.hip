@@ -25,6 +25,7 @@ inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 
 struct Tensor {
   float* d = nullptr;
+  void* planes = nullptr;  // bf16x3 engine: [3][rows][ld] bf16 planes of a GEMM weight (made on demand)
   std::vector<int64_t> shape;
   size_t n = 0;
   int64_t ld = 0;          // != 0: a [rows, cols] GEMM weight stored with this row stride (cols zero-padded to pad32)
@@ -70,6 +71,8 @@ struct SttranHandle {
   std::string err;
   std::map<std::string, Tensor> w;
   bool finalized = false;
+  int gemm_engine = STTRAN_GEMM_FP32_MFMA;
+  bool planes_ready = false;
   // derived parameters
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
@@ -258,6 +261,22 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
   if (gemm_slab_bytes() > h->slab.bytes) {
     HIPCK(hipStreamSynchronize(s));
     HIPCK(h->slab.ensure(gemm_slab_bytes()));
+  }
+  if (h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && M >= 512 && N >= 128 && !force_tile) {
+    // the weight (or a row range of it: the last decoder layer projects k|v and q separately) as bf16 planes
+    for (auto& kv : h->w) {
+      const Tensor& t = kv.second;
+      if (!t.planes || !t.ld || t.ld != pad32(K)) continue;
+      const int64_t rows = t.shape[0];
+      if (Wt < t.d || Wt >= t.d + rows * t.ld) continue;
+      const int64_t r0 = (Wt - t.d) / t.ld;
+      if ((Wt - t.d) % t.ld || r0 + N > rows) break;
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
+                   "gemm_x3_kernel<X3Tile<256,128,4,2>,EpiLinear>", M, N, K);
+      HIPCK(gemm_linear_x3(s, A, reinterpret_cast<const uint16_t*>(t.planes) + r0 * t.ld, t.ld, rows * t.ld, M, N, K, epi,
+                           h->slab.as<float>()));
+      return STTRAN_OK;
+    }
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
@@ -496,7 +515,10 @@ void sttran_destroy(SttranHandle* h) {
   if (!h) return;
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
-  for (auto& kv : h->w) if (kv.second.d) hipFree(kv.second.d);
+  for (auto& kv : h->w) {
+    if (kv.second.d) hipFree(kv.second.d);
+    if (kv.second.planes) hipFree(kv.second.planes);
+  }
   for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
                     &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
     b->release();
@@ -542,6 +564,7 @@ int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const
   }
   t.loaded = true;
   h->finalized = false;
+  h->planes_ready = false;
   return STTRAN_OK;
 }
 
@@ -652,6 +675,12 @@ int sttran_finalize_weights(SttranHandle* h) {
   return STTRAN_OK;
 }
 
+int sttran_set_gemm_engine(SttranHandle* h, int32_t engine) {
+  if (!h || (engine != STTRAN_GEMM_FP32_MFMA && engine != STTRAN_GEMM_BF16X3)) return STTRAN_ERR_INVALID;
+  h->gemm_engine = engine;
+  return STTRAN_OK;
+}
+
 int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes) {
   if (!h || max_pairs < 0 || max_boxes < 0) return STTRAN_ERR_INVALID;
   HIPCK(hipSetDevice(h->cfg.device));
@@ -719,6 +748,17 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   h->prof_stream = s;
   int rc;
   if (!h->finalized && (rc = sttran_finalize_weights(h))) return rc;
+  if (h->gemm_engine == STTRAN_GEMM_BF16X3 && !h->planes_ready) {
+    // split every GEMM weight into its three bf16 planes, once (also after a reload: load_tensor resets the flag)
+    for (auto& kv : h->w) {
+      Tensor& t = kv.second;
+      if (!t.ld || !t.d) continue;
+      const size_t bytes = (size_t)3 * t.shape[0] * t.ld * 2 + 256;
+      if (!t.planes) HIPCK(hipMalloc(&t.planes, bytes));
+      HIPCK(split_planes(s, t.d, t.ld, (int)t.shape[0], (int)t.shape[1], t.planes, t.ld));
+    }
+    h->planes_ready = true;
+  }
   if ((rc = ensure_workspace(h, P, B))) return rc;
 
   // ---- per-frame pair counts ---------------------------------------------------------------
@@ -1131,7 +1171,7 @@ int sttran_debug_gemm_x3(const float* A, int64_t lda, const int32_t* a_rowidx, c
   }
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
-  hipError_t err = gemm_linear_x3(s, GemmOperand{A, lda, a_rowidx}, planes, ldp, (int)M, (int)N, (int)K, e, slab);
+  hipError_t err = gemm_linear_x3(s, GemmOperand{A, lda, a_rowidx}, planes, ldp, N * ldp, (int)M, (int)N, (int)K, e, slab);
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 

@@ -76,6 +76,10 @@ class STTran:
         # 0.9 GB for `union_feat` at 64x36 -- on every call).  Off: convert, and warn once per key for copies > 16 MB.
         self.strict_inputs = False
         self._warned = set()
+        # GEMM engine of the nn.Linear layers: "fp32" (default: exact fp32 MFMA) or "bf16x3" (EXPERIMENT: fp32 emulated
+        # on the bf16 matrix pipe with three bf16 planes per operand -- fp32-level error, ~1.4x the GEMM rate)
+        self.gemm_engine = "fp32"
+        self._engine_set = None
         self._device = None
         self._handle = None
         self._sd = {}
@@ -168,6 +172,7 @@ class STTran:
         if self._handle is not None:
             self._lib.sttran_destroy(self._handle)
             self._handle = None
+            self._engine_set = None
 
     def __del__(self):
         try:
@@ -243,6 +248,9 @@ class STTran:
         clips packed by `pack_clips`, `clip_num_frames`."""
         self._ensure_handle()
         lib, h = self._lib, self._handle
+        if self._engine_set != self.gemm_engine:
+            nat.check(lib, h, lib.sttran_set_gemm_engine(h, {"fp32": 0, "bf16x3": 1}[self.gemm_engine]))
+            self._engine_set = self.gemm_engine
         f32, i64 = torch.float32, torch.int64
         if self._select:
             from .object_classifier import sgdet_select
