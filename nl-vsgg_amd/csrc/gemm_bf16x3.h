@@ -200,12 +200,14 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       load_step(set_load, t + 2);            // the set written to LDS during the previous step receives step t+2
       read_frags(cur, 0, fa, fb);
       // group 0: the split + LDS writes of step t+1 (raw data loaded during step t-1) ride under the MFMAs
-      mma_group(fa, fb, [&](int n) {
-        if (n < AV) store_a(set_store, n, nxt);
-        else if (n - AV < BV) store_b(set_store, n - AV, nxt);
+      constexpr int NMG = 6 * TM * TN;
+      mma_group(fa, fb, [&](int n) {                       // A pieces (split: VALU-heavy) spread over group 0
+        if (n % (NMG / AV) == 0 && n / (NMG / AV) < AV) store_a(set_store, n / (NMG / AV), nxt);
       });
       read_frags(cur, 1, fa, fb);
-      mma_group(fa, fb, [&](int) {});
+      mma_group(fa, fb, [&](int n) {                       // B pieces over group 1
+        if (n % (NMG / BV) == 0 && n / (NMG / BV) < BV) store_b(set_store, n / (NMG / BV), nxt);
+      });
       __syncthreads();
     };
     {
