@@ -23,6 +23,10 @@
 
 namespace sttran {
 
+#ifndef X3_ABLATE
+#define X3_ABLATE 0          // timing-only ablations (wrong results): 1 = no split arithmetic, 2 = no staging at all in the loop
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -148,6 +152,7 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
     f32x4 ra[2][AV];
     bf16x8 rb[2][BV];
     auto load_step = [&](int set, int step) {
+      if (X3_ABLATE == 2) return;
       const int st = step < nsteps ? step : 0;            // steps past the range re-read step 0 (never consumed)
 #pragma unroll
       for (int i = 0; i < AV; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + st * kBK);
@@ -156,12 +161,19 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
     };
     auto store_a = [&](int set, int i, unsigned char* stage) {
       bf16x4 h, m, l;
+      if (X3_ABLATE == 2) return;
+      if (X3_ABLATE == 1) {
+        h = *reinterpret_cast<const bf16x4*>(&ra[set][i]); m = h; l = *(reinterpret_cast<const bf16x4*>(&ra[set][i]) + 1);
+      } else
       split3(ra[set][i], h, m, l);
       *reinterpret_cast<bf16x4*>(stage + wa[i]) = h;
       *reinterpret_cast<bf16x4*>(stage + ROWS * 64 + wa[i]) = m;
       *reinterpret_cast<bf16x4*>(stage + 2 * ROWS * 64 + wa[i]) = l;
     };
-    auto store_b = [&](int set, int j, unsigned char* stage) { *reinterpret_cast<bf16x8*>(stage + wb[j]) = rb[set][j]; };
+    auto store_b = [&](int set, int j, unsigned char* stage) {
+      if (X3_ABLATE == 2) return;
+      *reinterpret_cast<bf16x8*>(stage + wb[j]) = rb[set][j];
+    };
     auto read_frags = [&](const unsigned char* stage, int g, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -199,12 +211,15 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       unsigned char* nxt = smem_raw + ((t + 1) & 1) * T::STAGE_BYTES;
       load_step(set_load, t + 2);            // the set written to LDS during the previous step receives step t+2
       read_frags(cur, 0, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);     // all twelve reads first: hipcc otherwise sinks each next to its MFMAs (12 exposed LDS latencies per step)
       // group 0: the split + LDS writes of step t+1 (raw data loaded during step t-1) ride under the MFMAs
       constexpr int NMG = 6 * TM * TN;
       mma_group(fa, fb, [&](int n) {                       // A pieces (split: VALU-heavy) spread over group 0
         if (n % (NMG / AV) == 0 && n / (NMG / AV) < AV) store_a(set_store, n / (NMG / AV), nxt);
       });
+      __builtin_amdgcn_sched_barrier(0);
       read_frags(cur, 1, fa, fb);
+      __builtin_amdgcn_sched_barrier(0);
       mma_group(fa, fb, [&](int n) {                       // B pieces over group 1
         if (n % (NMG / BV) == 0 && n / (NMG / BV) < BV) store_b(set_store, n / (NMG / BV), nxt);
       });
