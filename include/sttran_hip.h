@@ -287,7 +287,7 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
  * split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation
  * (csrc/gemm_bf16x3.h).  W [N,K] fp32 (row stride ldw) is split into planes inside the call (untimed by the caller's
  * events only if it warms up first: the planes are cached per W pointer). */
-int sttran_debug_gemm_x3(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
+int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
                          const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                          int32_t relu, void* stream);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */

@@ -1145,7 +1145,7 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
-int sttran_debug_gemm_x3(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
                          const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                          int32_t relu, void* stream) {
   if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < pad32(K) || ldw < K || (lda & 3)) return STTRAN_ERR_INVALID;

@@ -257,7 +257,7 @@ def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
     b = torch.randn(N, device="cuda", generator=g)
     res = torch.randn(M, N, device="cuda", generator=g)
     C3 = torch.full((M, N), float("nan"), device="cuda")
-    assert lib.sttran_debug_gemm_x3(_p(A), Kp, None, _p(W), K, _p(b), _p(res), _p(C3), M, N, K, 1, None) == 0
+    assert lib.sttran_debug_gemm_emulated(_p(A), Kp, None, _p(W), K, _p(b), _p(res), _p(C3), M, N, K, 1, None) == 0
     Wp = torch.zeros(N, Kp, device="cuda"); Wp[:, :K] = W
     C1 = torch.full((M, N), float("nan"), device="cuda")
     assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(Wp), Kp, _p(b), _p(res), _p(C1), M, N, K, 1, 0, None) == 0

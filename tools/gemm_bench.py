@@ -96,12 +96,12 @@ def main():
         if a.x3:
             Wd = W[:, :K].contiguous() if Kp != K else W
             for _ in range(3):
-                lib.sttran_debug_gemm_x3(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
+                lib.sttran_debug_gemm_emulated(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                lib.sttran_debug_gemm_x3(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
+                lib.sttran_debug_gemm_emulated(p(A), Kp, None, p(Wd), Wd.shape[1], p(b), pr, p(Cc), M, N, K, 0, None)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
