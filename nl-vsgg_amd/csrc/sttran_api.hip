@@ -423,8 +423,11 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
 }
 
 // DSG-DETR index maps (lib/dsg_detr.py:536-555).  Spatial sequences = frames (as above).  Temporal
-// sequences = one per object class present, its pairs in pair order; the PE row of a token is the
-// dense rank of the pair's subject box (one person box per frame) among the sequence's subjects.
+// sequences = one per object class present, its pairs in pair order.  PE rows are handed out by POSITION
+// (lib/dsg_detr.py:551-554: `[0]*count_0 + [1]*count_1 + ...` over the sorted unique subject boxes): token i
+// takes the dense rank of the i-th SMALLEST subject of its sequence -- its own subject's rank only when the
+// subject numbers ascend along the sequence (boxes stored frame by frame; golden dsgdetr_shuffled_boxes is the
+// other case).
 // Stored in the STTran slots: dec_off/dec_len = class sequences, dec_src = pair of each token,
 // need = PE row of each token, out_src = P + token of each pair.
 void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P,
@@ -451,8 +454,8 @@ void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int3
     const std::vector<int32_t>& pairs = kv.second;
     std::vector<int64_t> subj;
     for (int32_t p : pairs) subj.push_back(pair_idx[2 * (int64_t)p]);
+    std::sort(subj.begin(), subj.end());
     std::vector<int64_t> uniq(subj);
-    std::sort(uniq.begin(), uniq.end());
     uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
     cls_off.push_back((int32_t)tok_pair.size());
     cls_len.push_back((int32_t)pairs.size());

@@ -296,6 +296,22 @@ def make_entry(seed: int, pairs_per_frame, boxes_per_frame=None, mode: str = "pr
     return entry
 
 
+def shuffle_boxes(entry: dict, seed: int) -> dict:
+    """The same clip with its box rows stored in a random order (per-box arrays permuted, `pair_idx` renumbered;
+    the pair order -- and so `im_idx` -- is unchanged).  Box numbers are then no longer monotone in the frame:
+    the corner the DSG-DETR position index (`lib/dsg_detr.py:551-555`) treats positionally."""
+    B = entry["boxes"].shape[0]
+    perm = np.random.RandomState(seed).permutation(B)          # new row r holds old row perm[r]
+    inv = np.empty(B, dtype=np.int64)
+    inv[perm] = np.arange(B)
+    out = dict(entry)
+    for k in ("boxes", "labels", "scores", "features", "distribution", "pred_labels", "pred_scores"):
+        if k in entry and isinstance(entry[k], np.ndarray) and entry[k].shape[:1] == (B,):
+            out[k] = np.ascontiguousarray(entry[k][perm])
+    out["pair_idx"] = inv[entry["pair_idx"]]
+    return out
+
+
 def uniform_clip(seed: int, frames: int, boxes: int, **kw) -> dict:
     """T frames x N boxes (1 person + N-1 objects): the BASELINE.json synthetic configs."""
     return make_entry(seed, [boxes - 1] * frames, **kw)

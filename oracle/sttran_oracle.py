@@ -279,14 +279,17 @@ def torch_encoder_layer(x, sd, p):
 
 def dsg_detr_sequences(pair_idx, obj_class):
     """Temporal sequences of DSG-DETR (lib/dsg_detr.py:545-555): one per object class present, the
-    pairs of that class in pair order; position index = dense rank of the pair's subject box (one
-    person box per frame) inside the sequence."""
+    pairs of that class in pair order.  Position indices are handed out BY POSITION (`:551-554`): the
+    sequence's subject boxes are counted (`torch.unique(..., return_counts=True, sorted=True)`) and token i
+    gets the index of the count run it falls in -- `[0]*count_0 + [1]*count_1 + ...`.  That equals the dense
+    rank of the token's own subject only when the subject numbers ascend along the sequence (boxes stored
+    frame by frame); fixture `dsgdetr_shuffled_boxes` holds the other case."""
     seqs, poss = [], []
     for l in np.unique(obj_class):
         k = np.nonzero(obj_class == l)[0]
-        _, inv = np.unique(pair_idx[k, 0], return_inverse=True)
+        _, cnt = np.unique(pair_idx[k, 0], return_counts=True)
         seqs.append(k)
-        poss.append(inv.astype(np.int64))
+        poss.append(np.repeat(np.arange(len(cnt), dtype=np.int64), cnt))
     return seqs, poss
 
 

@@ -177,6 +177,9 @@ DSG_CASES = {
     "dsgdetr_4x3": (201, [2, 2, 2, 2]),
     "dsgdetr_ragged": (202, [3, 1, 4, 2, 5]),
     "dsgdetr_16x12": (203, [11] * 16),
+    # box rows stored in a random order: the subject numbers of a class sequence are no longer ascending, and
+    # lib/dsg_detr.py:551-555 hands out position indices by POSITION in the sequence (sorted counts), not per subject
+    "dsgdetr_shuffled_boxes": (204, [3, 1, 4, 2, 5, 3], 9),
 }
 
 
@@ -206,8 +209,10 @@ def build_reference_dsg(sd_np):
     return m
 
 
-def run_dsg_case(model, name, seed, counts):
+def run_dsg_case(model, name, seed, counts, shuffle_seed=None):
     e_np = syn.make_entry(seed, counts, mode="sgdet", im_idx_dtype=np.int64)
+    if shuffle_seed is not None:
+        e_np = syn.shuffle_boxes(e_np, shuffle_seed)
     entry = {k: torch.from_numpy(v) for k, v in e_np.items() if isinstance(v, np.ndarray) and k != "frame_counts"}
     grabbed = {}
     h = model.local_transformer.register_forward_hook(lambda m, a, o: grabbed.__setitem__("local_padded", o.detach().numpy().copy()))
@@ -223,6 +228,8 @@ def run_dsg_case(model, name, seed, counts):
     else:
         out["local_output_head"] = lo[:4]                      # keep the larger fixtures small
     out.update(pairs_per_frame=cnt.astype(np.int64), entry_seed=np.int64(seed), weight_seed=np.int64(WEIGHT_SEED))
+    if shuffle_seed is not None:
+        out["box_shuffle_seed"] = np.int64(shuffle_seed)
     for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
         assert np.isfinite(out[k]).all(), (name, k)
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
@@ -241,12 +248,12 @@ def main():
             models[mode] = build_reference_model(mode, sd)
         run_case(models[mode], name, seed, counts, mode, dump)
     dsg = None
-    for name, (seed, counts) in DSG_CASES.items():
+    for name, case in DSG_CASES.items():
         if sys.argv[1:] and name not in sys.argv[1:]:
             continue
         if dsg is None:
             dsg = build_reference_dsg(syn.make_dsg_detr_state_dict(WEIGHT_SEED))
-        run_dsg_case(dsg, name, seed, counts)
+        run_dsg_case(dsg, name, *case)
 
 
 if __name__ == "__main__":

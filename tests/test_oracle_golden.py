@@ -79,12 +79,14 @@ def test_unsorted_im_idx_rejected():
         orc.frame_counts_from_im_idx(np.array([0, 1, 0], dtype=np.float32))
 
 
-@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12"])
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes"])
 def test_dsg_detr_oracle_matches_reference(name, golden_dir):
     """DSG-DETR (lib/dsg_detr.py, sgdet branch) restatement vs the imported reference."""
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))
     sd = syn.make_dsg_detr_state_dict(int(g["weight_seed"]))
     entry = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
+    if "box_shuffle_seed" in g.files:
+        entry = syn.shuffle_boxes(entry, int(g["box_shuffle_seed"]))
     st = {}
     out = orc.dsg_detr_forward(entry, sd, stages=st)
     for k in ("attention_distribution", "spatial_distribution", "contacting_distribution", "distribution"):

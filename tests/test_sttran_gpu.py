@@ -220,7 +220,7 @@ def test_recall_identical_to_reference_pipeline(case, predcls, golden_dir):
             ref["result_dict"]["predcls_mean_recall"][str(k)], abs=1e-12)
 
 
-@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12"])
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes"])
 def test_dsg_detr_golden(name, golden_dir):
     """Second model on the shared kernels (BASELINE.json configs[4]): lib/dsg_detr.py sgdet branch."""
     if not torch.cuda.is_available():
@@ -233,6 +233,8 @@ def test_dsg_detr_golden(name, golden_dir):
     rep = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     m.taps = True
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
+    if "box_shuffle_seed" in g.files:      # box rows out of frame order: position indices go by position (dsg_detr.py:551-554)
+        e = syn.shuffle_boxes(e, int(g["box_shuffle_seed"]))
     pred = m(_cuda_entry(e))
     torch.cuda.synchronize()
     for k in OUT_KEYS + ("distribution",):
