@@ -38,6 +38,9 @@ CASES = {
     # the longest clip of the AG test split: 121 frames, 0..6 pairs per frame (empty frames and windows inside)
     "ragged_121": (108, [int(c) for c in np.random.default_rng(121).integers(0, 7, 121)], "predcls", False),
     "sgdet_16x12": (109, [11] * 16, "sgdet", False),
+    # round 2: the clip STARTS with frames that hold no pair (the j == 0 scatter of lib/transformer.py:180 is empty)
+    "leading_empty": (110, [0, 0, 3, 0, 2, 1], "predcls", True),
+    "sgdet_empty_frames": (111, [0, 2, 0, 3, 1], "sgdet", True),
 }
 
 
@@ -180,6 +183,7 @@ DSG_CASES = {
     # box rows stored in a random order: the subject numbers of a class sequence are no longer ascending, and
     # lib/dsg_detr.py:551-555 hands out position indices by POSITION in the sequence (sorted counts), not per subject
     "dsgdetr_shuffled_boxes": (204, [3, 1, 4, 2, 5, 3], 9),
+    "dsgdetr_empty_frames": (205, [0, 2, 0, 3, 1, 0, 2]),
 }
 
 
@@ -222,7 +226,8 @@ def run_dsg_case(model, name, seed, counts, shuffle_seed=None):
     out = {k: pred[k].numpy() for k in ("attention_distribution", "spatial_distribution", "contacting_distribution",
                                         "distribution")}
     cnt = np.asarray(counts)
-    lo = np.concatenate([grabbed["local_padded"][t, : cnt[t]] for t in range(len(cnt))], axis=0)
+    # one padded row per NON-EMPTY frame (lib/dsg_detr.py:537-538 loops over im_indices.unique())
+    lo = np.concatenate([grabbed["local_padded"][r, :n] for r, n in enumerate(cnt[cnt > 0])], axis=0)
     if lo.shape[0] <= 64:
         out["local_output"] = lo
     else:

@@ -9,7 +9,7 @@ from nl_vsgg_amd.lib import synthetic as syn
 from oracle import sttran_oracle as orc
 
 CASES = ["uniform_3x2", "ragged_5", "empty_frames", "two_frames", "sgdet_ragged", "uniform_16x12", "ragged_121",
-         "sgdet_16x12"]
+         "sgdet_16x12", "leading_empty", "sgdet_empty_frames"]
 TOL = 2e-5          # fp32 oracle vs fp32 torch-CPU reference: different summation orders only
 
 
@@ -79,7 +79,8 @@ def test_unsorted_im_idx_rejected():
         orc.frame_counts_from_im_idx(np.array([0, 1, 0], dtype=np.float32))
 
 
-@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes"])
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes",
+                                  "dsgdetr_empty_frames"])
 def test_dsg_detr_oracle_matches_reference(name, golden_dir):
     """DSG-DETR (lib/dsg_detr.py, sgdet branch) restatement vs the imported reference."""
     g = np.load(os.path.join(golden_dir, f"{name}.npz"))

@@ -48,7 +48,7 @@ def _cuda_entry(e):
             for k, v in e.items()}
 
 
-GOLDEN = ["uniform_3x2", "ragged_5", "empty_frames", "two_frames", "uniform_16x12", "ragged_121"]
+GOLDEN = ["uniform_3x2", "ragged_5", "empty_frames", "two_frames", "uniform_16x12", "ragged_121", "leading_empty"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -82,7 +82,7 @@ def test_golden_full_size_64x36(predcls, golden_dir):
         np.testing.assert_allclose(pred[k].cpu().numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["sgdet_ragged", "sgdet_16x12"])
+@pytest.mark.parametrize("name", ["sgdet_ragged", "sgdet_16x12", "sgdet_empty_frames"])
 def test_golden_sgdet(name, sgdet, golden_dir):
     g = np.load(os.path.join(golden_dir, f"sttran_{name}.npz"))
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
@@ -220,7 +220,8 @@ def test_recall_identical_to_reference_pipeline(case, predcls, golden_dir):
             ref["result_dict"]["predcls_mean_recall"][str(k)], abs=1e-12)
 
 
-@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes"])
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes",
+                                  "dsgdetr_empty_frames"])
 def test_dsg_detr_golden(name, golden_dir):
     """Second model on the shared kernels (BASELINE.json configs[4]): lib/dsg_detr.py sgdet branch."""
     if not torch.cuda.is_available():
