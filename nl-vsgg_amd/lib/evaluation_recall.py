@@ -121,7 +121,12 @@ class SceneGraphEvaluator:
         """`gt`: list over frames of `[ {'person_bbox'}, {'class','bbox','attention_relationship',
         'spatial_relationship','contacting_relationship'}, ... ]` (AG_Test schema,
         `dataloader/wk_action_genome.py:281-292`); `pred`: the dict returned by `STTran.forward`.
-        Frame `i` of `gt` is matched with the pairs whose `im_idx == i`."""
+        Frame `i` of `gt` is matched with the pairs whose `im_idx == i`.
+
+        One deliberate difference in SIDE EFFECTS: the reference rebinds `pred['attention_distribution']` to its
+        soft-max (`lib/evaluation_recall.py:400`), so evaluating the same dict twice soft-maxes twice there.  This
+        evaluator leaves `pred` untouched (the same `pred` can go to the host and the device evaluator); a caller that
+        read the soft-maxed entry back from the dict applies `softmax(dim=1)` itself."""
         att = _np(pred["attention_distribution"]).astype(np.float32)
         att = att - att.max(axis=1, keepdims=True)      # softmax over the 3 attention logits (:400)
         att = np.exp(att)
