@@ -343,6 +343,38 @@ def make_gt_annotation(seed: int, entry: dict) -> list:
     return gt
 
 
+def make_gt_annotation_hard(seed: int, entry: dict, jitter: float = 25.0, flip: float = 0.2) -> list:
+    """Ground truth the evaluator has to WORK for (the real SGDet situation): list position == frame id for EVERY
+    frame of the clip -- frames without a predicted pair get a person and 1..2 objects of their own, which no
+    prediction can hit (`lib/evaluation_recall.py:402` enumerates the list, `:428` selects `im_idx == idx`);
+    boxes are moved by up to `jitter` pixels per coordinate, so the 0.5 IoU test decides; a fraction `flip` of the
+    object classes differs from the detector's label."""
+    st = np.random.RandomState(seed)
+    base = make_gt_annotation(seed, entry)
+    present = sorted(set(entry["im_idx"].astype(np.int64).tolist()))
+    it = iter(base)
+    gt = []
+    for t in range(int(entry["num_frames"])):
+        if t in present:
+            frame = next(it)
+            frame[0]["person_bbox"] = (frame[0]["person_bbox"] + st.uniform(-jitter, jitter, (1, 4))).astype(np.float32)
+            for o in frame[1:]:
+                o["bbox"] = (o["bbox"] + st.uniform(-jitter, jitter, 4)).astype(np.float32)
+                if st.uniform() < flip:
+                    o["class"] = int(st.randint(2, NUM_OBJ_CLASSES))
+        else:
+            frame = [{"person_bbox": np.array([[10.0, 10.0, 100.0, 200.0]], dtype=np.float32)}]
+            for _ in range(int(st.randint(1, 3))):
+                x, y = st.uniform(0.0, 200.0, 2)
+                frame.append({"class": int(st.randint(2, NUM_OBJ_CLASSES)),
+                              "bbox": np.array([x, y, x + 50.0, y + 60.0], dtype=np.float32),
+                              "attention_relationship": st.randint(0, ATTENTION_CLASSES, 1),
+                              "spatial_relationship": np.unique(st.randint(0, SPATIAL_CLASSES, 2)),
+                              "contacting_relationship": np.unique(st.randint(0, CONTACT_CLASSES, 1))})
+        gt.append(frame)
+    return gt
+
+
 def make_detector_entry(seed: int, boxes_per_frame, feat_dim: int = 16, fmap_channels: int = 6, fmap_hw=(38, 50),
                         image_wh=(800.0, 600.0)) -> dict:
     """Raw detector output of one clip for the SGDet branch WITHOUT weak supervision (`lib/sttran.py:185-283`,

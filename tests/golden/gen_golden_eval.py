@@ -24,6 +24,11 @@ sys.path.insert(0, REF)
 from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
 
 CASES = {"uniform_16x12": "predcls", "ragged_5": "predcls", "sgdet_ragged": "sgdet"}
+# round 2: ground truth the matcher has to work for (synthetic.make_gt_annotation_hard: every frame present -- also
+# those without a predicted pair --, boxes jittered around the 0.5 IoU line, some classes flipped).
+# name -> (model fixture, mode, jitter)
+HARD_CASES = {"hard_empty_frames": ("empty_frames", "predcls", 6.0), "hard_sgdet_empty_frames": ("sgdet_empty_frames", "sgdet", 6.0),
+              "hard_uniform_16x12": ("uniform_16x12", "predcls", 8.0), "hard_sgdet_16x12": ("sgdet_16x12", "sgdet", 8.0)}
 OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
 ATT = [f"att{i}" for i in range(3)]
 SPA = [f"spa{i}" for i in range(6)]
@@ -79,6 +84,29 @@ def golden_draw():
     print("draw_union_boxes", out.shape, float(out.min()), float(out.max()))
 
 
+def run_reference_evaluator(RefEval, mode, e, gt, g):
+    for fr in gt:
+        for o in fr[1:]:
+            for k in ("attention_relationship", "spatial_relationship", "contacting_relationship"):
+                o[k] = torch.from_numpy(np.asarray(o[k]))
+    pred = {k: torch.from_numpy(e[k]) for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+        pred[k] = torch.from_numpy(g[k])
+    pred["pred_labels"], pred["pred_scores"] = pred["labels"], pred["scores"]
+    ev = RefEval(mode=mode, AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
+                 AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
+                 iou_threshold=0.5, constraint="with")
+    ev.register_container()
+    ev.evaluate_scene_graph(gt, pred)
+    ev.calculate_mean_recall()
+    out = {}
+    for key, val in ev.result_dict.items():
+        if key.endswith("_collect"):
+            continue
+        out[key] = {str(k): (v if isinstance(v, (int, float)) else [float(x) for x in v]) for k, v in val.items()}
+    return ev, out
+
+
 def main():
     golden_draw()
     build_bbox()
@@ -88,28 +116,22 @@ def main():
         e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
                            im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
         gt = syn.make_gt_annotation(1000 + int(g["entry_seed"]), e)
-        for fr in gt:
-            for o in fr[1:]:
-                for k in ("attention_relationship", "spatial_relationship", "contacting_relationship"):
-                    o[k] = torch.from_numpy(np.asarray(o[k]))
-        pred = {k: torch.from_numpy(e[k]) for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
-        for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
-            pred[k] = torch.from_numpy(g[k])
-        pred["pred_labels"], pred["pred_scores"] = pred["labels"], pred["scores"]
-        ev = RefEval(mode=mode, AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
-                     AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON,
-                     iou_threshold=0.5, constraint="with")
-        ev.register_container()
-        ev.evaluate_scene_graph(gt, pred)
-        ev.calculate_mean_recall()
-        out = {}
-        for key, val in ev.result_dict.items():
-            if key.endswith("_collect"):
-                continue
-            out[key] = {str(k): (v if isinstance(v, (int, float)) else [float(x) for x in v]) for k, v in val.items()}
+        ev, out = run_reference_evaluator(RefEval, mode, e, gt, g)
         with open(os.path.join(HERE, f"eval_{case}.json"), "w") as f:
             json.dump({"mode": mode, "gt_seed": 1000 + int(g["entry_seed"]), "result_dict": out}, f, indent=0)
         print(case, {k: round(float(np.mean(v)), 4) for k, v in ev.result_dict[mode + "_recall"].items()})
+    for case, (fixture, mode, jitter) in HARD_CASES.items():
+        g = np.load(os.path.join(HERE, f"sttran_{fixture}.npz"))
+        e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
+                           im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
+        gt = syn.make_gt_annotation_hard(2000 + int(g["entry_seed"]), e, jitter=jitter)
+        assert len(gt) == int(e["num_frames"])
+        ev, out = run_reference_evaluator(RefEval, mode, e, gt, g)
+        with open(os.path.join(HERE, f"eval_{case}.json"), "w") as f:
+            json.dump({"mode": mode, "fixture": fixture, "gt": "hard", "jitter": jitter, "gt_seed": 2000 + int(g["entry_seed"]),
+                       "result_dict": out}, f, indent=0)
+        print(case, {k: round(float(np.mean(v)), 4) for k, v in ev.result_dict[mode + "_recall"].items()},
+              {k: round(float(np.mean(v)), 4) for k, v in ev.result_dict[mode + "_recall_nogc"].items()})
 
 
 if __name__ == "__main__":

@@ -17,11 +17,14 @@ CON = [f"con{i}" for i in range(17)]
 
 def _run(case, golden_dir, perturb=0.0):
     ref = json.load(open(os.path.join(golden_dir, f"eval_{case}.json")))
-    g = np.load(os.path.join(golden_dir, f"sttran_{case}.npz"))
+    g = np.load(os.path.join(golden_dir, f"sttran_{ref.get('fixture', case)}.npz"))
     mode = ref["mode"]
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
                        im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
-    gt = syn.make_gt_annotation(ref["gt_seed"], e)
+    if ref.get("gt") == "hard":      # every frame present (also those without a predicted pair), jittered boxes, flipped classes
+        gt = syn.make_gt_annotation_hard(ref["gt_seed"], e, jitter=ref["jitter"])
+    else:
+        gt = syn.make_gt_annotation(ref["gt_seed"], e)
     pred = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
     for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
         pred[k] = g[k] + np.float32(perturb)
@@ -35,7 +38,10 @@ def _run(case, golden_dir, perturb=0.0):
     return ev, ref["result_dict"], mode
 
 
-@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5", "sgdet_ragged"])
+HARD = ["hard_empty_frames", "hard_sgdet_empty_frames", "hard_uniform_16x12", "hard_sgdet_16x12"]
+
+
+@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5", "sgdet_ragged"] + HARD)
 def test_recall_identical_to_reference(case, golden_dir):
     ev, ref, mode = _run(case, golden_dir)
     for t in ("recall", "recall_nogc", "semi_recall"):

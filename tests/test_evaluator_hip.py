@@ -94,14 +94,18 @@ def _to_dev(pred):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5", "sgdet_ragged"])
+@pytest.mark.parametrize("case", ["uniform_16x12", "ragged_5", "sgdet_ragged", "hard_empty_frames", "hard_sgdet_empty_frames",
+                                  "hard_uniform_16x12", "hard_sgdet_16x12"])
 def test_device_recall_identical_to_reference(case, golden_dir):
     ref = json.load(open(os.path.join(golden_dir, f"eval_{case}.json")))
-    g = np.load(os.path.join(golden_dir, f"sttran_{case}.npz"))
+    g = np.load(os.path.join(golden_dir, f"sttran_{ref.get('fixture', case)}.npz"))
     mode = ref["mode"]
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
                        im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
-    gt = syn.make_gt_annotation(ref["gt_seed"], e)
+    if ref.get("gt") == "hard":      # the reference evaluator on GT it has to work for: frames without predictions, IoU near 0.5
+        gt = syn.make_gt_annotation_hard(ref["gt_seed"], e, jitter=ref["jitter"])
+    else:
+        gt = syn.make_gt_annotation(ref["gt_seed"], e)
     pred = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
     for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
         pred[k] = g[k]
