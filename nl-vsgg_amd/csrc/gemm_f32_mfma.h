@@ -41,14 +41,10 @@ struct GemmOperand {
   const float* ptr;
   int64_t ld;          // row stride in floats (multiple of 4, 16-byte aligned base)
   const int* rowidx;   // optional gather: logical row r reads physical row rowidx[r]
-  int aux;             // B_UNION: number of pairs P (ld = pair stride K*49)
+  int aux;             // B_UNION_FLAT: number of pairs P (ld = pair stride K*49)
 };
 
 // B-operand kinds.  B_KMAJOR: rows of W[N][K], K-contiguous (nn.Linear weights, im2col rows).
-// B_UNION: the NCHW union_feat tensor U[P][K][49] read in place -- a 256-column tile is five pairs
-// (245 columns, 95.7 % full); per K-step each pair contributes one contiguous [32][49] slab
-// (6 272 bytes), copied flat into LDS; fragments are read with ds_read_b32 (lanes = consecutive
-// hw: conflict-free) using the same k-permutation as the A side.
 // B_CONV2: the 3x3 convolution of the mask branch (lib/sttran.py:342) as an implicit GEMM.  Row n of the B
 // operand is an output position (pair, oy, ox), column k = (ky, kx, ci) (the weights are permuted to match
 // when they are loaded); elements are gathered from the channel-last input [pair][7][7][128] on the fly (no
@@ -61,13 +57,19 @@ struct GemmOperand {
 // product path: weights are stored with zero-padded rows, and every activation buffer has a row stride of ceil32(K)
 // floats whose pad columns are zeroed once and never written (sttran_api.hip::ensure_workspace), so the K tail is
 // 0 x 0 whatever earlier calls left in the workspace.  B_KMAJOR (with the select) takes any operands.
-enum { B_KMAJOR = 0, B_UNION = 1, B_CONV2 = 2, B_KMAJOR_PAD = 3 };
+// B_UNION_FLAT: the 1x1 convolution union_func1 (lib/sttran.py:336,386) on the NCHW union_feat tensor U[P][K][49] read
+// in place: GEMM column = pair * 49 + hw, running straight over the pair borders (N = 49 P exactly: no padded columns,
+// all 256 output channels in ONE 256x128 tile, so U is fetched once).  A thread stages (column, 4 consecutive k): four
+// coalesced dword loads (the lanes of a wave walk 64 consecutive columns = hw) and ONE ds_write_b128 into the ordinary
+// K-major stage [column][k] -- the transposition happens in the registers, and the main loop (ds_read_b128 fragments)
+// is the one of the nn.Linear path.  (Round 1's variant -- 128x256 tiles of five whole pairs, [k][hw] slabs copied flat
+// into LDS and read back with ds_read_b32 -- fetched U twice and left 4.3 % of its columns empty: 116.5 -> 119.8 TFLOP/s.)
+enum { B_KMAJOR = 0, B_CONV2 = 2, B_KMAJOR_PAD = 3, B_UNION_FLAT = 4 };
 template <int BKIND> struct ConvGeo { static constexpr int KH = 1, S = 1, PAD = 0, HI = 1, HO = 1, CIN = 1, KREAL = 1; };
 template <> struct ConvGeo<B_CONV2> {   // Conv2d(128, 256, kernel 3, padding 1) on 7x7 -> 7x7
   static constexpr int KH = 3, S = 1, PAD = 1, HI = 7, HO = 7, CIN = 128, KREAL = 1152;
 };
-constexpr int kUPairs = 5, kUHW = 49, kUSlab = kBK * kUHW;     // 1568 floats per pair per K-step
-constexpr int kUStageB = kUPairs * kUSlab;                     // 7840 floats
+constexpr int kUHW = 49;                                       // positions of a 7x7 union feature map
 
 // ---- epilogues: called once per output element as epi(row, col, acc) --------------------
 struct EpiLinear {
@@ -126,15 +128,12 @@ struct EpiConvRelBn {
   }
 };
 
-// union_func1 as GEMM (B_UNION): row = out channel, col = 256*group + j, j < 245 = (pair in group, hw).
+// union_func1 as GEMM (B_UNION_FLAT): row = out channel, col = pair * 49 + hw.
 // V already holds the mask-conv branch: V[p][c][hw] += acc + bias[c]   (lib/sttran.py:386).
-struct EpiUnion {
+struct EpiUnionFlat {
   float* V; const float* bias; int C; int P;
   __device__ __forceinline__ void operator()(int row, int col, float v) const {
-    const int g = col >> 8, j = col & 255;
-    if (j >= kUPairs * kUHW) return;
-    const int q = j / kUHW, hw = j - q * kUHW, p = g * kUPairs + q;
-    if (p >= P) return;
+    const int p = col / kUHW, hw = col - p * kUHW;
     float* dst = V + ((int64_t)p * C + row) * kUHW + hw;
     *dst += v + bias[row];
   }
@@ -194,14 +193,15 @@ struct GemmTile {
   static constexpr int NT = WM * WN * 64;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int AV = BM * 8 / NT;                               // float4 loads per thread per step
-  static constexpr int BV = BKIND == B_UNION ? (kUStageB / 4 + NT - 1) / NT : BN * 8 / NT;
-  static constexpr int STAGE_B = BKIND == B_UNION ? kUStageB : BN * kLdsStride;
+  static constexpr int BV = BN * 8 / NT;
+  static constexpr int STAGE_B = BN * kLdsStride;
   static constexpr int STAGE = BM * kLdsStride + STAGE_B;              // floats per LDS stage
   static constexpr int LDS_BYTES = 2 * STAGE * 4;
-  static constexpr int GROUP_N = BKIND == B_UNION ? 1 : 8;            // tile_origin: N-tiles per group
+  static constexpr int GROUP_N = 8;                                   // tile_origin: N-tiles per group
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
   static_assert((BM * 8) % NT == 0, "A staging must divide evenly");
-  static_assert(BKIND == B_UNION ? BN == 256 : (BN * 8) % NT == 0, "B staging must divide evenly");
+  static_assert((BN * 8) % NT == 0, "B staging must divide evenly");
+  static_assert(BKIND != B_UNION_FLAT || (NT % BN == 0 && (NT / BN) * BV == 8), "B_UNION_FLAT: (column, k-group) per thread");
 };
 
 // XCD-aware, bijective remap of a linear block id: ids that are equal mod 8 share an XCD, so
@@ -214,7 +214,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // Tile index -> (M-tile, N-tile).  Consecutive indices sweep GN N-tiles of one M-tile, then the next M-tile, so the
 // 32 workgroups of an XCD (consecutive indices, see xcd_remap) work on a compact ~4 x 8 block of tiles whose A and
 // B panels are shared through that XCD's L2, instead of one long column of M-tiles that streams all of A for every
-// N panel.  GN = 1 keeps the M-fastest order (union conv: the two M-tiles of a pair group stay adjacent).
+// N panel.  GN = 1 keeps the M-fastest order.
 template <int GN>
 __device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
   if (GN <= 1) { tm = tile % tiles_m; tn = tile / tiles_m; return; }
@@ -255,9 +255,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
                int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, TM = T::TM, TN = T::TN, AV = T::AV, BV = T::BV;
-  constexpr bool UNION = T::BKIND == B_UNION;
   constexpr bool CONV = T::BKIND == B_CONV2;
   constexpr bool PADDED = T::BKIND == B_KMAJOR_PAD;
+  constexpr bool UFLAT = T::BKIND == B_UNION_FLAT;
   constexpr bool SWAP = EpiTraits<Epi>::swap;
   using Geo = ConvGeo<T::BKIND>;
   const int tid = threadIdx.x;
@@ -272,12 +272,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = wn * (BN / T::WN) + j * 32 + fr;
-    if constexpr (UNION) {
-      const int q = col / kUHW, hw = col - q * kUHW;
-      b_off[j] = BM * kLdsStride + (col < kUPairs * kUHW ? q * kUSlab + hw : 0) + fh * 4 * kUHW;
-    } else {
-      b_off[j] = (BM + col) * kLdsStride + fh * 4;
-    }
+    b_off[j] = (BM + col) * kLdsStride + fh * 4;
   }
 
   // Hybrid schedule: every workgroup first runs dp_per_wg WHOLE tiles (data-parallel, nothing parked),
@@ -327,13 +322,14 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      if constexpr (UNION) {
-        const int idx = tid + i * NT;              // float4 index inside the 5-pair stage
-        const int q = idx / (kUSlab / 4), f = idx - q * (kUSlab / 4);
-        const int p = (n0 / BN) * kUPairs + q;
-        vb[i] = idx < kUStageB / 4 && p < B.aux;
-        sb[i] = idx < kUStageB / 4 ? BM * kLdsStride + q * kUSlab + f * 4 : -1;
-        pb[i] = B.ptr + (int64_t)(vb[i] ? p : 0) * B.ld + f * 4;
+      if constexpr (UFLAT) {
+        // thread = (column tid % BN, k-group (tid / BN) * BV + i): columns past N read pair 0 (dropped by the epilogue)
+        const int col = tid % BN, kg = (tid / BN) * BV + i;
+        const int n = n0 + col;
+        vb[i] = n < N;
+        const int nn = vb[i] ? n : 0, p = nn / kUHW, hw = nn - p * kUHW;
+        sb[i] = (BM + col) * kLdsStride + kg * 4;
+        pb[i] = B.ptr + (int64_t)p * B.ld + kg * 4 * kUHW + hw;
       } else if constexpr (CONV) {
         const int g = n0 + (tid >> 3) + i * (NT >> 3);
         vb[i] = g < N;
@@ -364,11 +360,11 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         kb_src = ka;
       } else {
         // K-major rows: a float4 is all-in or all-out of [k_begin,k_end) because K % 4 == 0.
-        // Union slabs need K % 32 == 0 (checked by the launcher): a K-step is never partial.
+        // The union conv needs K % 32 == 0 (checked by the launcher): a K-step is never partial.
         kok_a = (k0 + kq4) < k_end;
-        kok_b = UNION ? k0 < k_end : kok_a;
+        kok_b = UFLAT ? k0 < k_end : kok_a;
         ka = kok_a ? k0 : 0;
-        kb_src = UNION ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
+        kb_src = UFLAT ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
       }
     };
     auto load_piece = [&](int n) {
@@ -387,6 +383,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         const bool ok = k0 < k_end && (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
         rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci : 0));
         cm[i] = ok ? 0xF : 0;
+      } else if constexpr (UFLAT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[n - AV][e] = pb[n - AV][kb_src + e * kUHW];
       } else {
         rb[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_src);
       }
@@ -396,7 +395,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         f32x4* dst = reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4);
         // the union conv and the 3x3 conv have M = 256 output channels (a whole number of tiles) and K % 32 == 0
         // (their launchers check both): every A piece is valid, like on the padded path
-        if constexpr (PADDED || UNION || CONV) *dst = ra[n];
+        if constexpr (PADDED || CONV || UFLAT) *dst = ra[n];
         else *dst = (va[n] && kok_a) ? ra[n] : zero4;
       } else {
         const int i = n - AV;
@@ -407,9 +406,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
           *reinterpret_cast<f32x4*>(stage + sb[i]) = v;
         } else if constexpr (PADDED) {
           *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
-        } else if constexpr (UNION) {
-          // pairs past P were loaded from pair 0 (clamped): their columns are dropped by EpiUnion, nothing to zero
-          if (sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
+        } else if constexpr (UFLAT) {
+          // columns past N were loaded from pair 0 (clamped): they are never stored by the epilogue, nothing to zero
+          *reinterpret_cast<f32x4*>(stage + sb[i]) = rb[i];
         } else {
           *reinterpret_cast<f32x4*>(stage + sb[i]) = (vb[i] && kok_b) ? rb[i] : zero4;
         }
@@ -422,12 +421,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         fa[i] = *reinterpret_cast<const f32x4*>(stage + a_off + i * 32 * kLdsStride + kb * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (UNION) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fb[j][e] = stage[b_off[j] + (kb * 8 + e) * kUHW];
-        } else {
-          fb[j] = *reinterpret_cast<const f32x4*>(stage + b_off[j] + kb * 8);
-        }
+        fb[j] = *reinterpret_cast<const f32x4*>(stage + b_off[j] + kb * 8);
       }
     };
 
@@ -452,17 +446,19 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
           for (int j = 0; j < TN; ++j) mfma1(acc[i][j], fa[i][e], fb[j][e]);
     };
 
-    // Operand kinds without per-step validity state (padded K-major rows, union slabs) prefetch TWO K-steps
+    // Operand kinds without per-step validity state (padded K-major rows, union columns, conv taps) prefetch TWO K-steps
     // ahead: the global loads of step t+2 are issued during step t into one of two register sets and written to
     // LDS during step t+1, so a load has a K-step and a half (~5 us) to arrive instead of half a K-step -- what
     // the operands need when they come from HBM rather than from a warm cache (tools/gemm_bench.py --cold).
-    constexpr bool DEEP = (PADDED || UNION || CONV) && PIPE == 1;
+    constexpr bool DEEP = (PADDED || CONV || UFLAT) && PIPE == 1;
+    // load slots of the two-deep pipeline: a B_UNION_FLAT piece is four dword loads, each its own slot
+    constexpr int NPL = AV + (UFLAT ? 4 * BV : BV);
     f32x4 ra2[DEEP ? AV : 1], rb2[DEEP ? BV : 1];       // second register set
     int cm2[BV];                                         // ... and its conv tap masks
     (void)cm2;
     // element offsets of K-step u of this range (the steps past its end read step 0 again, into an idle buffer)
     auto koff_a = [&](int u) { const int k0 = k_begin + u * kBK; return k0 < ks1 * kBK ? k0 : 0; };
-    auto koff_b = [&](int u) { return UNION ? koff_a(u) * kUHW : koff_a(u); };
+    auto koff_b = [&](int u) { return UFLAT ? koff_a(u) * kUHW : koff_a(u); };
     auto load_to = [&](int n, auto& RA, auto& RB, auto& CM, int ka_, int kb_) {
       if (n < AV) {
         RA[n] = *reinterpret_cast<const f32x4*>(pa[n] + ka_);
@@ -476,6 +472,9 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
         RB[i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci : 0));
         CM[i] = ok;
+      } else if constexpr (UFLAT) {
+        const int i = (n - AV) >> 2, e = (n - AV) & 3;       // slot = (piece, k inside the piece)
+        RB[i][e] = pb[i][kb_ + e * kUHW];
       } else {
         RB[n - AV] = *reinterpret_cast<const f32x4*>(pb[n - AV] + kb_);
       }
@@ -485,16 +484,15 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         *reinterpret_cast<f32x4*>(stage + ((tid >> 3) + n * (NT >> 3)) * kLdsStride + kq4) = RA[n];
       } else {
         const int i = n - AV;
-        if constexpr (UNION) { if (sb[i] >= 0) *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i]; }
-        else if constexpr (CONV) *reinterpret_cast<f32x4*>(stage + sb[i]) = CM[i] ? RB[i] : zero4;
+        if constexpr (CONV) *reinterpret_cast<f32x4*>(stage + sb[i]) = CM[i] ? RB[i] : zero4;
         else *reinterpret_cast<f32x4*>(stage + sb[i]) = RB[i];
       }
     };
     if constexpr (DEEP) {
 #pragma unroll
-      for (int n = 0; n < AV + BV; ++n) load_to(n, ra, rb, cm, koff_a(0), koff_b(0));
+      for (int n = 0; n < NPL; ++n) load_to(n, ra, rb, cm, koff_a(0), koff_b(0));
 #pragma unroll
-      for (int n = 0; n < AV + BV; ++n) load_to(n, ra2, rb2, cm2, koff_a(1), koff_b(1));
+      for (int n = 0; n < NPL; ++n) load_to(n, ra2, rb2, cm2, koff_a(1), koff_b(1));
 #pragma unroll
       for (int n = 0; n < AV + BV; ++n) store_from(n, smem, ra, rb, cm);
     } else {
@@ -553,13 +551,13 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
                 mfma1(acc[i][j], fa0[i][e], fb0[j][e]);
-                if (n < NP) load_to(n, RAL, RBL, CML, ka_, kb_);
+                if (n < NPL) load_to(n, RAL, RBL, CML, ka_, kb_);
                 ++n;
               }
 #pragma unroll
-          for (; n < NP; ++n) load_to(n, RAL, RBL, CML, ka_, kb_);
+          for (; n < NPL; ++n) load_to(n, RAL, RBL, CML, ka_, kb_);
 #pragma unroll
-          for (int q = 0; q < NP && q < NM; ++q) {
+          for (int q = 0; q < NPL && q < NM; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
           }

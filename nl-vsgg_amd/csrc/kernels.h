@@ -35,7 +35,7 @@ int num_cus();   // compute units of the current device (cached per ordinal)
 
 // ---- GEMM ------------------------------------------------------------------------------
 // 1..5: gemm_f32_mfma.h (register-staged); 6..9: gemm_dma.h (LDS-DMA staging, vector epilogue; padded operands only)
-enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_UNION = 5,
+enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_RESERVED = 5,
        TILE_D128x128 = 6, TILE_D256x128 = 7, TILE_D128x64 = 8, TILE_D64x64 = 9, TILE_COUNT = 10 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);

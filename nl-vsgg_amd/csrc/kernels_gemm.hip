@@ -9,7 +9,7 @@ using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
 using TConv2 = GemmTile<256, 128, 4, 2, B_CONV2>;   // conv3x3 as implicit GEMM: all 256 output channels in one tile (B gathered once)
-using TUnion = GemmTile<128, 256, 2, 4, B_UNION>;   // 8 waves, wave tile 64x64, B = NCHW union_feat slabs
+using TUnionFlat = GemmTile<256, 128, 4, 2, B_UNION_FLAT>;   // all 256 channels in one tile, columns = pair * 49 + hw
 
 int num_cus() {
   static int cus[kMaxDevices] = {};
@@ -29,9 +29,9 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   const int64_t ksteps = (K + kBK - 1) / kBK;
   static const int env_tile = getenv("STTRAN_GEMM_TILE") ? atoi(getenv("STTRAN_GEMM_TILE")) : 0;   // experiments only
   static const int env_gen = getenv("STTRAN_GEMM_GEN") ? atoi(getenv("STTRAN_GEMM_GEN")) : 0;      // 1 = old tiles only, 2 = DMA tiles only
-  if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT && env_tile != TILE_UNION) force_tile = env_tile;
+  if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT && env_tile != TILE_RESERVED) force_tile = env_tile;
   for (int t = 1; t < TILE_COUNT; ++t) {
-    if (t == TILE_UNION) continue;
+    if (t == TILE_RESERVED) continue;
     if (force_tile && t != force_tile) continue;
     if (!force_tile && env_gen == 1 && is_dma_tile(t)) continue;
     if (!force_tile && env_gen == 2 && !is_dma_tile(t)) continue;
@@ -156,16 +156,15 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
   // N = 26: only the 64x64 tile makes sense (sttran_api.hip forces it); padded operands
   return launch_tile<GemmTile<64, 64, 2, 2, B_KMAJOR_PAD>, EpiScalar4<EpiHeads>>(s, TILE_64x64, A, B, M, N, K, slab, EpiScalar4<EpiHeads>{epi});
 }
-// union_func1: M = 256 out channels (A = W[256][K]), N = ceil(P/5) groups x 256 columns, stream-K
-// over (tile, K-step) like every other GEMM
+// union_func1: M = 256 out channels (A = W[256][K], one M-tile), N = 49 P columns (pair, hw) read in place from the
+// NCHW tensor (B_UNION_FLAT), hybrid data-parallel + stream-K schedule like every other GEMM
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V, int P,
                              int K, float* slab) {
-  if (K % kBK != 0 || P <= 0) return hipErrorInvalidValue;      // (M = 256 = 2 x BM: no A piece is ever invalid)
-  const int groups = (P + kUPairs - 1) / kUPairs;
+  if (K % kBK != 0 || P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
   GemmOperand A{W, (int64_t)K, nullptr, 0};
   GemmOperand B{U, (int64_t)K * kUHW, nullptr, P};
-  EpiUnion epi{V, bias, 256, P};
-  return launch_tile<TUnion, EpiUnion>(s, TILE_UNION, A, B, 256, groups * 256, K, slab, epi);
+  EpiUnionFlat epi{V, bias, 256, P};
+  return launch_tile<TUnionFlat, EpiUnionFlat>(s, TILE_256x128, A, B, 256, P * kUHW, K, slab, epi);
 }
 
 // Conv2d(128,256,k3,p1) -> ReLU -> BN as implicit GEMM: A = conv.4.weight.view(256, 1152), B gathered

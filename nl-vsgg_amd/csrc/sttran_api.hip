@@ -903,7 +903,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   }
   {
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
-                 "gemm_sk_kernel<GemmTile<128,256,2,4,B_UNION>,EpiUnion>", 256, P * 49, FD);
+                 "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
     HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                             h->slab.as<float>()));
   }
