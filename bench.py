@@ -6,10 +6,10 @@
 
 A *step* is one pass of the hot path (`STTran.forward`) over one batch of synthetic clips resident
 in HBM.  Workload of the line's `value` (default, BASELINE.json configs[1]): clips of 16 frames x 12 boxes
-x 2048-d region features (P = 176 pairs per clip), `--clips-per-step` clips per pass (default 16).
-`--workload 64x36` selects configs[3]'s clip shape instead.  The default run ALSO measures the 64x36
-clip (one clip per step) in the same process and reports it under `workloads["64x36"]` -- north_star's
-scaling target is quoted on that workload --, the DSG-DETR model of configs[4] under
+x 2048-d region features (P = 176 pairs per clip), `--clips-per-step` clips per pass (default 64; `batch_sweep`
+in the line shows 1 / 16 / 64).  `--workload 64x36` selects configs[3]'s clip shape instead (default 4 clips per
+pass).  The default run ALSO measures the 64x36 clip in the same process and reports it under
+`workloads["64x36"]` -- north_star's scaling target is quoted on that workload --, the DSG-DETR model of configs[4] under
 `workloads["dsgdetr_16x12"]`, a 256-clip sample of the configs[2] stand-in (Action-Genome-test-split-shaped clips,
 model + device evaluator) under `workloads["ag_split_shaped"]`, and the one-clip-per-pass rate of the 16x12 clip
 (the reference's own batch size) under `one_clip_per_pass`: every BASELINE config has a number in the line.
@@ -46,7 +46,12 @@ from nl_vsgg_amd.lib.sttran import STTran, pack_clips  # noqa: E402
 
 CLASSES = ["__background__"] + [f"c{i}" for i in range(36)]
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-SHAPES = {"16x12": (16, 12, 16), "64x36": (64, 36, 1)}      # frames, boxes per frame, default clips per step
+# frames, boxes per frame, default clips per step.  A step batches ~10 k pairs (64 clips of 16x12 = 11 264 pairs, 4 clips of
+# 64x36 = 8 960): the clip is the BASELINE one, the batch is this framework's (`pack_clips`); measured on one MI355X the
+# 16x12 rate goes 15.8 k (1 clip) -> 28.3 k (8) -> 30.2 k (16) -> 31.3 k (32) -> 32.0 k (64) -> 32.5 k (128) frames/s as
+# tile quantisation and the stream-K fix-ups amortise; `batch_sweep` in the line re-measures 1 / 16 / default every run.
+SHAPES = {"16x12": (16, 12, 64), "64x36": (64, 36, 4)}
+SWEEP_CPS = {"16x12": 16, "64x36": 1}                           # the smaller batch of `batch_sweep` (round 1-2 defaults)
 
 
 def device_clip(T, N, gen, device):
@@ -107,7 +112,7 @@ def cpu_baseline(T, N, sd, budget_s=24.0):
 def ag_split_sample(device, n_clips):
     """BASELINE configs[2] stand-in on a sample of the split: synthetic clips with the Action Genome test split's
     frames-per-clip (tests/golden/ag_test_clip_lengths.json: the first `n_clips` of its 1 737 clips), 1..6 pairs per frame,
-    packed 16 per forward, predictions straight into the device evaluator (tools/ag_split_bench.py runs all of them)."""
+    packed 64 per forward, predictions straight into the device evaluator (tools/ag_split_bench.py runs all of them)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ag_split_bench as ag
     from nl_vsgg_amd.lib.evaluation_recall_hip import SceneGraphEvaluator_HIP
@@ -131,8 +136,8 @@ def ag_split_sample(device, n_clips):
     warm = model(pack_clips([dict(c[0]) for c in chunk[:2]])); del warm
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(0, len(chunk), 16):
-        group = chunk[i:i + 16]
+    for i in range(0, len(chunk), 64):
+        group = chunk[i:i + 64]
         preds = unpack_predictions(model(pack_clips([dict(c[0]) for c in group])))
         for (e, gt), p in zip(group, preds):
             p.update(pair_idx=e["pair_idx"], im_idx=e["im_idx"], boxes=e["boxes"], labels=e["labels"], scores=e["scores"])
@@ -144,7 +149,7 @@ def ag_split_sample(device, n_clips):
     return {"value": frames / dt, "seconds": dt, "clips": len(chunk), "frames": frames,
             "pairs": sum(int(c[0]["pair_idx"].shape[0]) for c in chunk),
             "config": {"workload": "Action-Genome-test-split-shaped synthetic clips (frames per clip from ag_test_id.pkl, 1..6 pairs "
-                                   "per frame), STTran PredCls + device Recall@K evaluator, 16 clips per forward, features "
+                                   "per frame), STTran PredCls + device Recall@K evaluator, 64 clips per forward, features "
                                    "resident in HBM; the real split's annotations / features are not shipped with the reference"},
             "recall_with_constraint": {str(k): round(float(v), 4) for k, v in ev.summary()["recall"].items()}}
 
@@ -319,6 +324,23 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
         res["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1,
                                     "note": "same clip shape with clips_per_step = 1: the reference's batch "
                                             "(dataloader/wk_action_genome.py:622-627); latency-bound, one clip cannot fill 256 CUs"}
+        model(dict(batch))                              # restore the cached layout of the batch
+
+    # ---- the batch size between one clip and the default (the default of rounds 1-2): a few steps, not `value` ---
+    if one_clip and world == 1 and cps > SWEEP_CPS[workload] > 1:
+        c2 = SWEEP_CPS[workload]
+        small = pack_clips([dict(c) for c in clips[:c2]])
+        for _ in range(2):
+            model(dict(small))
+        torch.cuda.synchronize()
+        n2 = max(5, min(steps, 20))
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            model(dict(small))
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / n2
+        res["batch_sweep"] = [{"clips_per_step": c2, "value": c2 * T / dt2, "ms_per_step": 1e3 * dt2}]
+        del small
         model(dict(batch))                              # restore the cached layout of the batch
 
     # ---- PCIe-inclusive rate (never `value`): inputs start in pinned host memory each step ----------
@@ -504,6 +526,14 @@ def main():
     if world > 1:
         result["scaling_note"] = ("weak scaling: every rank runs the same per-GPU workload on its own clips, so value ~ N x "
                                   "the 1-GPU value by construction unless the host glue or the per-step all-gather contends")
+    if "batch_sweep" in main_res:                        # 1 clip / the round 1-2 default / this run's batch, one list
+        sweep = []
+        if "one_clip_per_pass" in main_res:
+            sweep.append({"clips_per_step": 1, "value": main_res["one_clip_per_pass"]["value"],
+                          "ms_per_step": main_res["one_clip_per_pass"]["ms_per_step"]})
+        sweep += main_res["batch_sweep"]
+        sweep.append({"clips_per_step": cps, "value": main_res["value"], "ms_per_step": main_res["ms_per_step"]})
+        result["batch_sweep"] = sweep
     for k in ("allgather_ms", "allgather_bytes_per_rank", "one_clip_per_pass", "pcie_inclusive", "pcie_inclusive_overlapped",
               "roofline", "reference_arithmetic"):
         if k in main_res:
