@@ -423,7 +423,10 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
             with open(os.path.join(pdir, pmc[-1])) as f:
                 pj = json.load(f)
             cls = pj["classes"].get("gemm")
-            if cls:
+            # per-launch bytes scale with the batch: only a PMC file taken at this run's clips per step applies
+            # (files older than round 2's r2_d carry no `clips_per_step`: they were taken at 16 / 1 clips)
+            pmc_cps = pj.get("clips_per_step") or {"16x12": 16, "64x36": 1}[workload]
+            if cls and pmc_cps == cps:
                 traffic, traffic_src, traffic_commit = cls["hbm_bytes_per_launch"], f"profiles/{pmc[-1]}", pj.get("commit")
         by_kernel, by_shape = by_kernel_tables(entries, prof["forwards"])
         res["roofline"] = {

@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<w>_FETCH_SIZE -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<w>_WRITE_SIZE -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_<w>_FETCH_SIZE gpurun_out/pmc_<w>_WRITE_SIZE [commit] > profiles/rN_pmc_traffic_<w>.json
+    python tools/pmc_traffic.py gpurun_out/pmc_<w>_FETCH_SIZE gpurun_out/pmc_<w>_WRITE_SIZE [commit [clips_per_step]] > profiles/rN_pmc_traffic_<w>.json
 (the profiled command is `bench.py --profile-only-batch`: warm-up + timed steps of one workload, nothing else; the
 optional third argument stamps the JSON with the commit the library was built from)
 
@@ -46,7 +46,10 @@ def main():
                      "hbm_bytes_per_launch": (rd + wr) / n}
     json.dump({"note": "FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 per launch (fix-up launches folded into "
                        "their GEMM); all forwards of the profiled bench run (bench.py --profile-only-batch)",
-               "commit": sys.argv[3] if len(sys.argv) > 3 else None, "classes": out}, sys.stdout, indent=1)
+               "commit": sys.argv[3] if len(sys.argv) > 3 else None,
+               # clips per step of the profiled run (bench.py attaches `traffic` only to a run of the same batch)
+               "clips_per_step": int(sys.argv[4]) if len(sys.argv) > 4 else None,
+               "classes": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

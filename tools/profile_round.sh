@@ -1,7 +1,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-C=9357b6b
+C=e152953
 # 1. kernel traces (per-step averages: --profile-only-batch)
 for w in 16x12 64x36; do
   st=20; [ $w = 64x36 ] && st=10
@@ -14,7 +14,8 @@ for w in 16x12 64x36; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/r2d_pmc_${w}_$c -- python3 bench.py --workload $w --steps 3 --warmup 1 --profile-only-batch > /dev/null 2> gpurun_out/r2d_pmc_${w}_$c.err
   done
-  python3 tools/pmc_traffic.py gpurun_out/r2d_pmc_${w}_FETCH_SIZE gpurun_out/r2d_pmc_${w}_WRITE_SIZE $C > gpurun_out/r2d_pmc_traffic_$w.json
+  cps=64; [ $w = 64x36 ] && cps=4
+  python3 tools/pmc_traffic.py gpurun_out/r2d_pmc_${w}_FETCH_SIZE gpurun_out/r2d_pmc_${w}_WRITE_SIZE $C $cps > gpurun_out/r2d_pmc_traffic_$w.json
 done
 # 4. MFMA busy passes
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do
