@@ -116,6 +116,29 @@ def test_hip_select_equals_oracle_fresh_seeds(seed, counts, ge):
 
 
 @pytest.mark.gpu
+def test_hip_select_equals_oracle_many_seeds():
+    """40 random detector outputs (1..6 frames, 0..40 boxes per frame, both NMS comparison flavours): selection, order,
+    labels, humans and pairs bit-identical to the oracle (small features: only the index work is under test)"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.object_classifier import sgdet_select
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        counts = [int(c) for c in rng.integers(0, 41, int(rng.integers(1, 7)))]
+        if counts[-1] == 0:
+            counts[-1] = int(rng.integers(1, 41))      # the reference sizes the clip by its LAST box (lib/sttran.py:196)
+        ge = bool(trial & 1)
+        e = syn.make_detector_entry(900 + trial, counts, feat_dim=8, fmap_channels=2)
+        ref = oc.objcls_select(e["boxes"], e["distribution"], e["features"], e["pred_labels"], ge=ge)
+        out = sgdet_select(_to_cuda(e), nms_ge=ge)
+        torch.cuda.synchronize()
+        for k in INT_KEYS + EXACT_KEYS:
+            np.testing.assert_array_equal(out[k].cpu().numpy().reshape(np.asarray(ref[k]).shape), ref[k],
+                                          err_msg=f"trial {trial} counts {counts} ge {ge}: {k}")
+
+
+@pytest.mark.gpu
 def test_hip_roi_align_full_width():
     """2048 channels at the detector's feature-map size, rois touching and crossing the borders"""
     torch = pytest.importorskip("torch")

@@ -104,6 +104,33 @@ def test_oracle_fresh_seeds(counts, predcls, weights):
         np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
 
 
+def test_oracle_many_random_clips(predcls, sgdet, weights):
+    """16 random ragged clips (1..14 frames, 0..9 pairs per frame, empty frames anywhere but last), predcls and
+    sgdet alternating, each against the fp64 oracle -- and all of them packed into ONE forward per mode"""
+    from oracle import sttran_oracle as orc
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    rng = np.random.default_rng(2025)
+    kept = {"predcls": [], "sgdet": []}
+    for trial in range(16):
+        counts = [int(c) for c in rng.integers(0, 10, int(rng.integers(1, 15)))]
+        if counts[-1] == 0:
+            counts[-1] = 1
+        mode = "sgdet" if trial & 1 else "predcls"
+        e = syn.make_entry(5000 + trial, counts, mode=mode, im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
+        ref = orc.sttran_forward(e, weights, mode=mode, dtype=np.float64)
+        pred = (sgdet if mode == "sgdet" else predcls)(_cuda_entry(e))
+        torch.cuda.synchronize()
+        for k in OUT_KEYS + (("distribution",) if mode == "sgdet" else ()):
+            np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=f"trial {trial} {counts} {k}")
+        kept[mode].append((e, ref))
+    for mode, model in (("predcls", predcls), ("sgdet", sgdet)):
+        packed = unpack_predictions(model(pack_clips([_cuda_entry(e) for e, _ in kept[mode]])))
+        torch.cuda.synchronize()
+        for (e, ref), p in zip(kept[mode], packed):
+            for k in OUT_KEYS:
+                np.testing.assert_allclose(p[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
+
+
 def test_packed_clips_equal_single_clips(predcls):
     """A batch of clips in one pass gives, clip by clip, bitwise the single-clip results whenever the
     same kernels/tiles run; across different tile plans the values agree to rounding."""
