@@ -293,6 +293,39 @@ def test_dsg_detr_oracle_larger_clip():
         DSG(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES)
 
 
+def test_dsg_detr_many_random_clips():
+    """10 random ragged clips through DSG-DETR vs the fp64 oracle, half of them with the box rows stored out of frame
+    order (position indices by position, lib/dsg_detr.py:551-554), then all ten packed into one forward"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    from oracle import sttran_oracle as orc
+    sd = syn.make_dsg_detr_state_dict(7)
+    m = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    rng = np.random.default_rng(31)
+    kept = []
+    for trial in range(10):
+        counts = [int(c) for c in rng.integers(0, 8, int(rng.integers(1, 10)))]
+        if counts[-1] == 0:
+            counts[-1] = 2
+        e = syn.make_entry(7000 + trial, counts, mode="sgdet", im_idx_dtype=np.int64)
+        if trial & 1:
+            e = syn.shuffle_boxes(e, trial)
+        ref = orc.dsg_detr_forward(e, sd, dtype=np.float64)
+        pred = m(_cuda_entry(e))
+        torch.cuda.synchronize()
+        for k in OUT_KEYS:
+            np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=f"trial {trial} {counts} {k}")
+        kept.append((e, ref))
+    packed = unpack_predictions(m(pack_clips([_cuda_entry(e) for e, _ in kept])))
+    torch.cuda.synchronize()
+    for (e, ref), p in zip(kept, packed):
+        for k in OUT_KEYS:
+            np.testing.assert_allclose(p[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
+
+
 def test_dsg_detr_packed_clips_equal_single_clips():
     """class sequences are built per (clip, class): clips packed into one pass give the single-clip results"""
     if not torch.cuda.is_available():
