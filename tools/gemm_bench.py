@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fp32 MFMA GEMM (sttran_debug_gemm_padded: the product's operand layout) per (shape, tile).
 Used to tune the tile planner (csrc/kernels_gemm.hip); run on the GPU box:
-    python tools/gemm_bench.py [--shapes big|path64|path16|path16x8] [--tiles 1,2,3,4,5]"""
+    python tools/gemm_bench.py [--shapes big|path64|path16|path16x8|path16x16|path16x64] [--tiles 1,2,3,4,5]"""
 import argparse
 import ctypes as C
 import os
@@ -29,6 +29,7 @@ SHAPES = {
     "path16": path_shapes(176, 330),
     "path16x8": path_shapes(1408, 2640),
     "path16x16": path_shapes(2816, 5280),
+    "path16x64": path_shapes(11264, 21120),
 }
 
 
