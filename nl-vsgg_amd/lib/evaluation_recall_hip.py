@@ -59,6 +59,22 @@ class PackedGroundTruth:
             frames.append([{"person_bbox": self.boxes[b0][None, :].copy()}] + objs)
         return frames
 
+    @staticmethod
+    def concat(parts):
+        """Ground truth of several clips as ONE (frames in order): the counterpart of `pack_clips` on the prediction
+        side, so a packed forward can go to the evaluator in one call (frame f of clip c becomes frame
+        sum(frames of clips < c) + f, exactly how `pack_clips` renumbers `im_idx`)."""
+        parts = list(parts)
+        box_off, rel_off = [np.zeros(1, np.int32)], [np.zeros(1, np.int32)]
+        b = r = 0
+        for p in parts:
+            box_off.append(p.box_off[1:] + b)
+            rel_off.append(p.rel_off[1:] + r)
+            b += int(p.box_off[-1]); r += int(p.rel_off[-1])
+        return PackedGroundTruth(np.concatenate(box_off), np.concatenate([p.boxes for p in parts]).reshape(-1, 4),
+                                 np.concatenate([p.classes for p in parts]), np.concatenate(rel_off),
+                                 np.concatenate([p.rels for p in parts]).reshape(-1, 3))
+
     def on(self, device):
         key = str(device)
         if key not in self._dev:
@@ -153,6 +169,7 @@ class SceneGraphEvaluator_HIP(SceneGraphEvaluator):
         return pack_ground_truth(gt, self)
 
     def evaluate_scene_graph(self, gt, pred):
+        self._poll()
         packed = gt if isinstance(gt, PackedGroundTruth) else pack_ground_truth(gt, self)
         att = pred["attention_distribution"]
         if not (hasattr(att, "is_cuda") and att.is_cuda):
@@ -197,18 +214,64 @@ class SceneGraphEvaluator_HIP(SceneGraphEvaluator):
         if rc != nat.STTRAN_OK:
             raise nat.SttranError(rc, "sttran_eval_recall failed")
         # the launch reads these tensors asynchronously: keep them alive until the flush
-        self._pending.append((packed, flags, (att, spa, con, pair, im, boxes, classes, scores)))
+        host = done = None
+        if R * 9 >= self.EAGER_BYTES:
+            # a big table (a packed call): start its copy-back now and tally it as soon as it has landed -- under the
+            # forwards that follow -- instead of leaving all host work to the end of the loop
+            host = torch.empty((R, 9), dtype=torch.uint8, pin_memory=True)
+            host.copy_(flags, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        self._pending.append((packed, flags, (att, spa, con, pair, im, boxes, classes, scores), host, done))
+
+    EAGER_BYTES = 1 << 16
+
+    def _poll(self):
+        """Tally, in order, the pending tables whose copy-back has completed (never blocks)."""
+        while self._pending and self._pending[0][4] is not None and self._pending[0][4].query():
+            packed, _, _, host, _ = self._pending.pop(0)
+            tally_hit_flags(self, self._rd, packed, host.numpy())
+
+    def evaluate_packed(self, gts, packed_pred):
+        """A `pack_clips` forward scored in ONE call: `gts` = the clips' ground truths in pack order (lists of frames or
+        PackedGroundTruth; or one PackedGroundTruth already made by `PackedGroundTruth.concat`), `packed_pred` = the dict
+        the model returned for the packed entry.  Same containers, same order of the per-frame lists as one
+        `evaluate_scene_graph` call per clip (the reference's loop, `tools/test_STTran.py:88`) -- at 1/64 of the host
+        work per clip."""
+        if isinstance(gts, PackedGroundTruth):
+            packed = gts
+        else:
+            parts = [g if isinstance(g, PackedGroundTruth) else pack_ground_truth(g, self) for g in gts]
+            want = packed_pred.get("clip_num_frames")
+            if want is not None and [p.num_frames for p in parts] != [int(x) for x in want]:
+                raise ValueError("ground-truth frames per clip do not match the packed entry's clip_num_frames")
+            packed = PackedGroundTruth.concat(parts)
+        if "num_frames" in packed_pred and packed.num_frames != int(packed_pred["num_frames"]):
+            raise ValueError("ground truth and packed prediction disagree on the number of frames")
+        self.evaluate_scene_graph(packed, packed_pred)
 
     def flush(self):
         """Copy the pending hit tables back (one D2H) and add them to the containers."""
         if not self._pending:
             return
         pending, self._pending = self._pending, []
-        flags = torch.cat([p[1] for p in pending]).cpu().numpy()          # synchronises
-        status = int(self._status.item())
+        status = int(self._status.item())                                  # synchronises
         self._status.zero_()
         if status & 1:
             raise nat.SttranError(6, f"a frame has more than {self.max_pairs_per_frame} pairs")
         if status & 2:
             raise IndexError("pair_idx out of range of boxes")
-        tally_hit_flags(self, self._rd, [p[0] for p in pending], flags)
+        lazy = []                                  # consecutive small tables: one concatenated copy-back
+
+        def drain():
+            if lazy:
+                tally_hit_flags(self, self._rd, [p[0] for p in lazy], torch.cat([p[1] for p in lazy]).cpu().numpy())
+                lazy.clear()
+        for p in pending:                          # in call order: the per-frame lists must keep it
+            if p[3] is None:
+                lazy.append(p)
+            else:
+                drain()
+                p[4].synchronize()
+                tally_hit_flags(self, self._rd, p[0], p[3].numpy())
+        drain()

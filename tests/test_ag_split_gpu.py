@@ -5,7 +5,7 @@ with the reference): frames per clip from `datasets/AG/ag_test_id
 clips packed 16 per forward, predictions straight into the device evaluator.
 
 Checked: (1) the device evaluator's `result_dict` equals the host evaluator's on the same predictions, list by
-list; (2) the HIP outputs of sampled clips (the 121-frame one, a 3-frame one and two others) are within 1e-3 of the
+list -- called once per clip and once per pack of 16 clips (`evaluate_packed`); (2) the HIP outputs of sampled clips (the 121-frame one, a 3-frame one and two others) are within 1e-3 of the
 fp64 oracle on the same inputs; (3) a clip's packed result equals its single-clip result to rounding."""
 import json
 import os
@@ -70,16 +70,20 @@ def test_ag_split_shaped_loop(golden_dir):
     kept = {}                                                    # clip position -> packed-run outputs (numpy)
     sample = {0, len(clips) - 1, 5, 23}                          # longest (121 frames), shortest (3 frames), two others
     assert clips[0][0]["num_frames"] == 121 and clips[-1][0]["num_frames"] == 3
+    ev_pack = SceneGraphEvaluator_HIP(**kw)                      # the same loop with ONE evaluator call per pack
+    ev_pack.register_container()
     for i in range(0, len(clips), PACK):
         group = clips[i:i + PACK]
-        preds = unpack_predictions(model(pack_clips([dict(c[0]) for c in group])))
+        packed_pred = model(pack_clips([dict(c[0]) for c in group]))
+        ev_pack.evaluate_packed([gt for _, gt in group], packed_pred)
+        preds = unpack_predictions(packed_pred)
         for j, ((e, gt), p) in enumerate(zip(group, preds)):
             p.update(pair_idx=e["pair_idx"], im_idx=e["im_idx"], boxes=e["boxes"], labels=e["labels"], scores=e["scores"])
             ev_dev.evaluate_scene_graph(gt, p)
             ev_host.evaluate_scene_graph(gt.to_annotation(ev_host), p)
             if i + j in sample:
                 kept[i + j] = {k: p[k].cpu().numpy() for k in OUT_KEYS}
-    ev_dev.calculate_mean_recall(); ev_host.calculate_mean_recall()
+    ev_dev.calculate_mean_recall(); ev_host.calculate_mean_recall(); ev_pack.calculate_mean_recall()
     torch.cuda.synchronize()
 
     # (1) identical evaluation: every recall list of every metric, the per-predicate collections and the mean-recall tables
@@ -96,6 +100,9 @@ def test_ag_split_shaped_loop(golden_dir):
             assert float(x) == float(y), path
     assert set(ev_host.result_dict) == set(ev_dev.result_dict)
     same(ev_host.result_dict, ev_dev.result_dict, ())
+    same(ev_host.result_dict, ev_pack.result_dict, ())           # one call per pack == one call per clip
+    with pytest.raises(ValueError):                              # a pack whose ground truth misses a clip is refused
+        ev_pack.evaluate_packed([gt for _, gt in clips[:PACK - 1]], model(pack_clips([dict(c[0]) for c in clips[:PACK]])))
     assert len(ev_host.result_dict["predcls_recall"][20]) == sum(c[0]["num_frames"] for c in clips)
 
     # (2) sampled clips vs the fp64 oracle, (3) packed == single
