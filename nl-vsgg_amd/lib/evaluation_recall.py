@@ -116,6 +116,18 @@ class SceneGraphEvaluator:
             self.result_dict[f"{m}_{t}_collect"] = {k: [[] for _ in range(self.num_rel)] for k in KS}
             self.result_dict[f"{m}_{t}_list"] = {k: [] for k in KS}
 
+    # ---- a pack of clips in one call -------------------------------------------------------------
+    def evaluate_packed(self, gts, packed_pred):
+        """`packed_pred` = the dict the model returned for a `pack_clips` entry, `gts` = the clips' ground truths (lists of
+        frames) in pack order.  `pack_clips` numbers the frames of the pack consecutively and offsets `pair_idx`, so the
+        packed dict IS one long clip for `evaluate_scene_graph` once the ground-truth lists are chained: same containers,
+        same order as one call per clip (`tools/test_STTran.py:88`)."""
+        gts = [g if isinstance(g, (list, tuple)) else g.to_annotation(self) for g in gts]
+        want = packed_pred.get("clip_num_frames") if hasattr(packed_pred, "get") else None
+        if want is not None and [len(g) for g in gts] != [int(x) for x in want]:
+            raise ValueError("ground-truth frames per clip do not match the packed entry's clip_num_frames")
+        self.evaluate_scene_graph([frame for g in gts for frame in g], packed_pred)
+
     # ---- per-clip accumulation ------------------------------------------------------------------
     def evaluate_scene_graph(self, gt, pred):
         """`gt`: list over frames of `[ {'person_bbox'}, {'class','bbox','attention_relationship',

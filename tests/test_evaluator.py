@@ -71,3 +71,38 @@ def test_print_stats_runs(golden_dir):
     ev, _, _ = _run("ragged_5", golden_dir)
     text = ev.print_stats()
     assert "R @ 20" in text and "type=Recall(Main)" in text
+
+
+def test_evaluate_packed_equals_per_clip_calls():
+    """a `pack_clips` entry scored in one call == its clips scored one by one (host evaluator, CPU tensors)"""
+    torch = pytest.importorskip("torch")
+    from nl_vsgg_amd.lib.sttran import pack_clips
+    rng = np.random.default_rng(3)
+    clips, gts, preds = [], [], []
+    for c, counts in enumerate([[3, 1, 4], [2, 2], [1, 5, 2, 2]]):
+        e = syn.make_entry(640 + c, counts, geometry_only=True)
+        P = sum(counts)
+        e["features"] = np.zeros((e["boxes"].shape[0], 4), np.float32)          # pack_clips sizes the box offsets by it
+        gts.append(syn.make_gt_annotation(1640 + c, e))
+        d = {"attention_distribution": (3 * rng.standard_normal((P, 3))).astype(np.float32),
+             "spatial_distribution": rng.random((P, 6)).astype(np.float32),
+             "contacting_distribution": rng.random((P, 17)).astype(np.float32)}
+        preds.append(d)
+        clips.append({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) and k != "frame_counts" else v) for k, v in e.items()})
+    kw = dict(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON, AG_attention_predicates=ATT,
+              AG_spatial_predicates=SPA, AG_contacting_predicates=CON, iou_threshold=0.5)
+    one, many = SceneGraphEvaluator(**kw), SceneGraphEvaluator(**kw)
+    one.register_container(); many.register_container()
+    for e, gt, d in zip(clips, gts, preds):
+        p = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+        p.update(d)
+        one.evaluate_scene_graph(gt, p)
+    packed = pack_clips(clips)
+    for k in preds[0]:
+        packed[k] = np.concatenate([d[k] for d in preds])
+    many.evaluate_packed(gts, packed)
+    one.calculate_mean_recall(); many.calculate_mean_recall()
+    for key in one.result_dict:
+        assert one.result_dict[key] == many.result_dict[key], key
+    with pytest.raises(ValueError):
+        many.evaluate_packed(gts[:2], packed)
