@@ -36,9 +36,16 @@ struct X3Weights {
   int64_t plane_stride;     // rows * ldp
 };
 
-template <int BM_, int BN_, int WM_, int WN_>
+// A-operand kinds.  A_ROWS: K-contiguous fp32 rows (every nn.Linear input).  A_UNION_FLAT: the NCHW union_feat tensor
+// U[P][K][49] read in place as the ACTIVATION operand of union_func1 -- GEMM row = pair * 49 + hw, running over the pair
+// borders like B_UNION_FLAT of gemm_f32_mfma.h (there the tensor is the B operand; here the weights are, because they
+// are the side that arrives pre-split).  A thread stages (row, 4 consecutive k): four coalesced dword loads (the lanes of
+// a wave walk consecutive rows = hw), split in registers, one 8-byte write per plane.
+enum { A_ROWS = 0, A_UNION_FLAT = 1 };
+
+template <int BM_, int BN_, int WM_, int WN_, int AKIND_ = A_ROWS>
 struct X3Tile {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, AKIND = AKIND_;
   static constexpr int NT = WM * WN * 64;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int ROWS = BM + BN;
@@ -48,6 +55,27 @@ struct X3Tile {
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
   static constexpr int GROUP_N = 8;
   static_assert((BM * 8) % NT == 0 && (3 * BN * 4) % NT == 0, "staging must divide evenly");
+  static_assert(AKIND != A_UNION_FLAT || (NT % BM == 0 && (NT / BM) * AV == 8), "A_UNION_FLAT: (row, k-group) per thread");
+};
+
+// union_func1 with the roles of the bf16x3 engine: row = pair * 49 + hw, col = out channel; `V += acc + bias` as
+// "accumulate onto V" (kInit, see EpiUnionFlat): V[p][c][hw] is read into the accumulators of the K range that starts a
+// tile and stored by the epilogue.  Lanes hold consecutive rows = consecutive hw of one channel: 128-byte runs.
+struct EpiUnionRows {
+  float* V; const float* bias; int C;
+  static constexpr bool kVector = true;       // swapped MFMA ports (the engine's only form); vec() is four scalar stores
+  static constexpr bool kInit = true;
+  __device__ __forceinline__ float* at(int row, int col) const {
+    const int p = row / kUHW, hw = row - p * kUHW;
+    return V + ((int64_t)p * C + col) * kUHW + hw;
+  }
+  __device__ __forceinline__ bool init_on() const { return true; }
+  __device__ __forceinline__ float init(int row, int col) const { return *at(row, col); }
+  __device__ __forceinline__ void operator()(int row, int col, float v) const { *at(row, col) = v + bias[col]; }
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) (*this)(row, col + c, v[c]);
+  }
 };
 
 // x -> (hi, mid, lo) bf16 planes, four elements at a time
@@ -122,10 +150,19 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
     int wa[AV];                                     // LDS byte offset of the 8-byte piece inside a plane
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      const int row = (tid >> 3) + i * (NT >> 3);
-      const int g = m0 + row;
-      pa[i] = A.ptr + (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + ks0 * kBK + (tid & 7) * 4;
-      wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
+      if constexpr (T::AKIND == A_UNION_FLAT) {
+        // thread = (row tid % BM, k-group (tid / BM) * AV + i); rows past M read pair 0 (never stored by the epilogue)
+        const int row = tid % BM, kg = (tid / BM) * AV + i;
+        const int n = m0 + row < M ? m0 + row : 0;
+        const int p = n / kUHW, hw = n - p * kUHW;
+        pa[i] = A.ptr + (int64_t)p * A.ld + (int64_t)(ks0 * kBK + kg * 4) * kUHW + hw;
+        wa[i] = row * 64 + (((kg >> 1) ^ ((row >> 2) & 3)) * 16) + (kg & 1) * 8;
+      } else {
+        const int row = (tid >> 3) + i * (NT >> 3);
+        const int g = m0 + row;
+        pa[i] = A.ptr + (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + ks0 * kBK + (tid & 7) * 4;
+        wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
+      }
     }
     const __bf16* pb[BV];
     int wb[BV];                                     // LDS byte offset inside the stage (plane included)
@@ -145,6 +182,22 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if constexpr (EpiInit<Epi>::value) {
+      // C += A B (EpiUnionRows): the K range that starts a tile accumulates onto the output's old values
+      if (ks0 == 0 && epi.init_on()) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = m0 + wm * (BM / T::WM) + fr + i * 32;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int col = n0 + wn * (BN / T::WN) + 4 * fh + j * 32 + 8 * (e >> 2) + (e & 3);
+              if (r < M && col < N) acc[i][j][e] = epi.init(r, col);
+            }
+        }
+      }
+    }
 
     // Two K-steps of global prefetch: the raw loads of step t+2 are issued at the top of step t into one of two register
     // sets; the set loaded one step earlier (step t+1) is split into planes and written to the other LDS stage under
@@ -155,7 +208,14 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       if (X3_ABLATE == 2) return;
       const int st = step < nsteps ? step : 0;            // steps past the range re-read step 0 (never consumed)
 #pragma unroll
-      for (int i = 0; i < AV; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + st * kBK);
+      for (int i = 0; i < AV; ++i) {
+        if constexpr (T::AKIND == A_UNION_FLAT) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[set][i][e] = pa[i][(st * kBK + e) * kUHW];
+        } else {
+          ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + st * kBK);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < BV; ++j) rb[set][j] = *reinterpret_cast<const bf16x8*>(pb[j] + st * kBK);
     };

@@ -58,6 +58,9 @@ hipError_t split_planes(hipStream_t s, const float* W, int64_t ld, int rows, int
 // planes points at the first needed weight row of plane 0; plane_stride = elements between planes (rows_total * ldp)
 hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int64_t plane_stride, int M,
                           int N, int K, const EpiLinear& epi, float* slab);
+// union_func1 on the same engine: planes = [3][256][K] bf16 of union_func1.weight
+hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const void* planes, const float* bias, float* V, int P, int K,
+                                float* slab);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // pair_idx/labels (int64) -> int32 gather indices + the two class-embedding column blocks of x

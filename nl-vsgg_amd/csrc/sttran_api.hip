@@ -760,6 +760,14 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       if (!t.planes) HIPCK(hipMalloc(&t.planes, bytes));
       HIPCK(split_planes(s, t.d, t.ld, (int)t.shape[0], (int)t.shape[1], t.planes, t.ld));
     }
+    {   // the 1x1 union conv's weight [256, feat_dim, 1, 1] is a [256, feat_dim] GEMM operand too (feat_dim % 32 == 0)
+      Tensor& t = h->w["union_func1.weight"];
+      const int64_t FDp = c.feat_dim;
+      if (t.d) {
+        if (!t.planes) HIPCK(hipMalloc(&t.planes, (size_t)3 * 256 * FDp * 2 + 256));
+        HIPCK(split_planes(s, t.d, FDp, 256, (int)FDp, t.planes, FDp));
+      }
+    }
     h->planes_ready = true;
   }
   if ((rc = ensure_workspace(h, P, B))) return rc;
@@ -902,10 +910,16 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
   }
   {
+    const Tensor& wu = h->w["union_func1.weight"];
+    const bool x3 = h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && wu.planes && P * 49 >= 512;
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
-                 "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
-    HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
-                            h->slab.as<float>()));
+                 x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_UNION_FLAT>,EpiUnionRows>"
+                    : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
+    if (x3)
+      HIPCK(launch_union_conv_x3(s, in->union_feat, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD, h->slab.as<float>()));
+    else
+      HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+                              h->slab.as<float>()));
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
                        epi_plain(X0 + 1024, LD, W(h, "vr_fc.bias"))))) return rc;
