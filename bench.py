@@ -568,8 +568,8 @@ def main():
             w = run_workload(env, model, args.model, "16x12", cps, max(5, min(args.steps, 20)), min(args.warmup, 3), roofline=False)
             w.pop("unit", None)
             w["max_abs_diff_vs_fp32_engine"] = diff
-            w["note"] = ("EXPERIMENT, opt-in (model.gemm_engine = 'bf16x3'): nn.Linear GEMMs with M >= 512 on "
-                         "v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 planes, six cross products, fp32 "
+            w["note"] = ("EXPERIMENT, opt-in (model.gemm_engine = 'bf16x3'): nn.Linear GEMMs with M >= 512, the union 1x1 conv and "
+                         "the conv3x3 on v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 planes, six cross products, fp32 "
                          "accumulate; error vs fp64 no larger than the exact fp32-MFMA engine's (tests/test_kernels_gpu.py)")
             result["workloads"]["16x12_bf16x3"] = w
         except Exception as e:

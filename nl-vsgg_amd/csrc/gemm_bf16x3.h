@@ -41,7 +41,10 @@ struct X3Weights {
 // borders like B_UNION_FLAT of gemm_f32_mfma.h (there the tensor is the B operand; here the weights are, because they
 // are the side that arrives pre-split).  A thread stages (row, 4 consecutive k): four coalesced dword loads (the lanes of
 // a wave walk consecutive rows = hw), split in registers, one 8-byte write per plane.
-enum { A_ROWS = 0, A_UNION_FLAT = 1 };
+// A_CONV2: the 3x3 convolution of the mask branch (lib/sttran.py:342) as an implicit GEMM with the activations as the A
+// operand: GEMM row = (pair, oy, ox), column k = (ky, kx, ci) gathered from the channel-last input [pair][7][7][128] on
+// the fly (one tap = 128 channels = 4 K-steps; a tap outside the image is a zero piece).
+enum { A_ROWS = 0, A_UNION_FLAT = 1, A_CONV2 = 2 };
 
 template <int BM_, int BN_, int WM_, int WN_, int AKIND_ = A_ROWS>
 struct X3Tile {
@@ -61,6 +64,20 @@ struct X3Tile {
 // union_func1 with the roles of the bf16x3 engine: row = pair * 49 + hw, col = out channel; `V += acc + bias` as
 // "accumulate onto V" (kInit, see EpiUnionFlat): V[p][c][hw] is read into the accumulators of the K range that starts a
 // tile and stored by the epilogue.  Lanes hold consecutive rows = consecutive hw of one channel: 128-byte runs.
+// conv3x3 -> ReLU -> eval-BatchNorm with the engine's roles (row = (pair, position), col = out channel), stored
+// channel-major into V[p][c][49] like EpiConvRelBn
+struct EpiConvRows {
+  float* V; const float* bias; const float* scale; const float* shift; int C;
+  static constexpr bool kVector = true;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    const int p = row / kUHW, pos = row - p * kUHW;
+    V[((int64_t)p * C + col) * kUHW + pos] = relu_nan(v + bias[col]) * scale[col] + shift[col];
+  }
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) (*this)(row, col + c, v[c]);
+  }
+};
 struct EpiUnionRows {
   float* V; const float* bias; int C;
   static constexpr bool kVector = true;       // swapped MFMA ports (the engine's only form); vec() is four scalar stores
@@ -148,9 +165,18 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
 
     const float* pa[AV];
     int wa[AV];                                     // LDS byte offset of the 8-byte piece inside a plane
+    int cy[AV], cx[AV];                             // A_CONV2: input row / column of tap (0, 0) for this output position
+    (void)cy; (void)cx;
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      if constexpr (T::AKIND == A_UNION_FLAT) {
+      if constexpr (T::AKIND == A_CONV2) {
+        const int row = (tid >> 3) + i * (NT >> 3);
+        const int g = m0 + row < M ? m0 + row : 0;
+        const int pr = g / kUHW, pos = g - pr * kUHW, oy = pos / 7, ox = pos - oy * 7;
+        cy[i] = oy - 1; cx[i] = ox - 1;
+        pa[i] = A.ptr + (int64_t)pr * (128 * kUHW) + (tid & 7) * 4;
+        wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
+      } else if constexpr (T::AKIND == A_UNION_FLAT) {
         // thread = (row tid % BM, k-group (tid / BM) * AV + i); rows past M read pair 0 (never stored by the epilogue)
         const int row = tid % BM, kg = (tid / BM) * AV + i;
         const int n = m0 + row < M ? m0 + row : 0;
@@ -204,12 +230,20 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
     // the MFMAs of step t.
     f32x4 ra[2][AV];
     bf16x8 rb[2][BV];
+    bool aok[2][AV];                                // A_CONV2: the piece's tap lies inside the image
+    (void)aok;
     auto load_step = [&](int set, int step) {
       if (X3_ABLATE == 2) return;
       const int st = step < nsteps ? step : 0;            // steps past the range re-read step 0 (never consumed)
 #pragma unroll
       for (int i = 0; i < AV; ++i) {
-        if constexpr (T::AKIND == A_UNION_FLAT) {
+        if constexpr (T::AKIND == A_CONV2) {
+          const int ks = ks0 + st, tap = ks >> 2, ky = tap / 3, kx = tap - ky * 3;      // wave-uniform
+          const int iy = cy[i] + ky, ix = cx[i] + kx;
+          const bool ok = (unsigned)iy < 7u && (unsigned)ix < 7u;
+          ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + (ok ? (iy * 7 + ix) * 128 : 0) + (ks & 3) * kBK);
+          aok[set][i] = ok;
+        } else if constexpr (T::AKIND == A_UNION_FLAT) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ra[set][i][e] = pa[i][(st * kBK + e) * kUHW];
         } else {
@@ -224,6 +258,8 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       if (X3_ABLATE == 2) return;
       if (X3_ABLATE == 1) {
         h = *reinterpret_cast<const bf16x4*>(&ra[set][i]); m = h; l = *(reinterpret_cast<const bf16x4*>(&ra[set][i]) + 1);
+      } else if constexpr (T::AKIND == A_CONV2) {
+        split3(aok[set][i] ? ra[set][i] : f32x4{0.f, 0.f, 0.f, 0.f}, h, m, l);
       } else
       split3(ra[set][i], h, m, l);
       *reinterpret_cast<bf16x4*>(stage + wa[i]) = h;

@@ -59,6 +59,8 @@ hipError_t split_planes(hipStream_t s, const float* W, int64_t ld, int rows, int
 hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* planes, int64_t ldp, int64_t plane_stride, int M,
                           int N, int K, const EpiLinear& epi, float* slab);
 // union_func1 on the same engine: planes = [3][256][K] bf16 of union_func1.weight
+hipError_t launch_mask_conv2_x3(hipStream_t s, const void* planes, const float* c2, const float* bias, const float* scale,
+                                const float* shift, float* V, int P, float* slab);
 hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const void* planes, const float* bias, float* V, int P, int K,
                                 float* slab);
 

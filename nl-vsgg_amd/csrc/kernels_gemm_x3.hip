@@ -63,4 +63,15 @@ hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const void* plane
   return launch_x3<X3Tile<128, 256, 2, 4, A_UNION_FLAT>, EpiUnionRows>(s, A, B, P * kUHW, 256, K, slab, epi);
 }
 
+// Conv2d(128,256,k3,p1) -> ReLU -> BN on the same engine: planes = [3][256][1152] bf16 of the (ky, kx, ci)-ordered weight,
+// c2 = channel-last [P][7][7][128]
+hipError_t launch_mask_conv2_x3(hipStream_t s, const void* planes, const float* c2, const float* bias, const float* scale,
+                                const float* shift, float* V, int P, float* slab) {
+  if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16(planes) || !al16(c2)) return hipErrorInvalidValue;
+  GemmOperand A{c2, 0, nullptr, 0};
+  X3Weights B{reinterpret_cast<const __bf16*>(planes), 1152, (int64_t)256 * 1152};
+  EpiConvRows epi{V, bias, scale, shift, 256};
+  return launch_x3<X3Tile<128, 256, 2, 4, A_CONV2>, EpiConvRows>(s, A, B, P * kUHW, 256, 1152, slab, epi);
+}
+
 }  // namespace sttran

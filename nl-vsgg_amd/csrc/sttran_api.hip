@@ -77,6 +77,7 @@ struct SttranHandle {
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
   float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
+  void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
   // workspace
@@ -522,6 +523,7 @@ void sttran_destroy(SttranHandle* h) {
     if (kv.second.d) hipFree(kv.second.d);
     if (kv.second.planes) hipFree(kv.second.planes);
   }
+  if (h->w4_planes) hipFree(h->w4_planes);
   for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
                     &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
     b->release();
@@ -768,6 +770,10 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
         HIPCK(split_planes(s, t.d, FDp, 256, (int)FDp, t.planes, FDp));
       }
     }
+    if (h->w4_perm) {   // conv3x3 weight in its (ky, kx, ci) K order
+      if (!h->w4_planes) HIPCK(hipMalloc(&h->w4_planes, (size_t)3 * 256 * 1152 * 2 + 256));
+      HIPCK(split_planes(s, h->w4_perm, 1152, 256, 1152, h->w4_planes, 1152));
+    }
     h->planes_ready = true;
   }
   if ((rc = ensure_workspace(h, P, B))) return rc;
@@ -905,9 +911,15 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                                    h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
+    const bool x3 = h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && h->w4_planes && P * 49 >= 512;
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
-                 "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
-    HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
+                 x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_CONV2>,EpiConvRows>"
+                    : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
+    if (x3)
+      HIPCK(launch_mask_conv2_x3(s, h->w4_planes, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
+                                 h->slab.as<float>()));
+    else
+      HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
   }
   {
     const Tensor& wu = h->w["union_func1.weight"];

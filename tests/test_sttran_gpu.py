@@ -431,3 +431,28 @@ def test_bf16x3_engine_matches_reference(name, weights, golden_dir):
         d_x3 = np.abs(outs[0][k].cpu().numpy() - g[k]).max()
         d_fp = np.abs(exact[k].cpu().numpy() - g[k]).max()
         assert d_x3 < 4 * d_fp + 2e-6, (k, d_x3, d_fp)
+
+
+def test_bf16x3_convolutions_match_the_exact_engine(weights):
+    """the two convolutions of the emulated engine (union 1x1 with the NCHW tensor as its A operand, conv3x3 gather) pinned
+    by themselves: the fused pair features `rel_features` (columns 1024:1536 = vr_fc over the conv outputs) of a ragged
+    packed batch against the exact engine on the same inputs, and against the fp64 oracle"""
+    from oracle import sttran_oracle as orc
+    from nl_vsgg_amd.lib.sttran import pack_clips
+    m = _model("predcls", weights)
+    m.taps = True
+    clips = [syn.make_entry(8100 + i, c, real_masks=True) for i, c in enumerate([[3, 1, 4, 2], [5, 5, 5], [2, 0, 6, 1, 1]])]
+    batch = pack_clips([_cuda_entry(e) for e in clips])
+    got = {}
+    for eng in ("fp32", "bf16x3"):
+        m.gemm_engine = eng
+        got[eng] = m(dict(batch))["_tap_rel_features"].cpu().numpy()
+    m.gemm_engine = "fp32"
+    m.taps = False
+    assert got["fp32"].shape[0] == sum(int(e["pair_idx"].shape[0]) for e in clips) and got["fp32"].shape[0] * 49 >= 512
+    np.testing.assert_allclose(got["bf16x3"], got["fp32"], atol=2e-5, rtol=0)
+    st = {}
+    orc.sttran_forward(clips[1], weights, dtype=np.float64, stages=st)
+    p0 = int(clips[0]["pair_idx"].shape[0])
+    ref = st["rel_features"]
+    np.testing.assert_allclose(got["bf16x3"][p0:p0 + ref.shape[0]], ref, atol=2e-5, rtol=0)
