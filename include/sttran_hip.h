@@ -132,12 +132,12 @@ int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const
 int sttran_finalize_weights(SttranHandle* h);
 /* Writes a '\n'-separated list of still-missing state-dict keys into buf; returns their count. */
 int sttran_missing_keys(SttranHandle* h, char* buf, int64_t buflen);
-/* GEMM engine of the nn.Linear layers (no reference counterpart).  STTRAN_GEMM_FP32_MFMA (default): exact fp32 on
+/* GEMM engine of the nn.Linear layers and the two convolutions (no reference counterpart).  STTRAN_GEMM_FP32_MFMA (default): exact fp32 on
  * v_mfma_f32_32x32x2_f32.  STTRAN_GEMM_BF16X3 (EXPERIMENT, opt-in): fp32 EMULATED on the bf16 matrix pipe -- every
  * operand split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32
  * accumulation (csrc/gemm_bf16x3.h); measured error against fp64 no larger than the exact engine's.  The weights are
- * split once (at the next forward); activations are split on the fly.  Convolutions, attention and the small
- * GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
+ * split once (at the next forward); activations are split on the fly.  Attention, the 7x7 mask convolution and the
+ * small GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
 enum { STTRAN_GEMM_FP32_MFMA = 0, STTRAN_GEMM_BF16X3 = 1 };
 int sttran_set_gemm_engine(SttranHandle* h, int32_t engine);
 /* Pre-size the workspace (otherwise grown on demand by forward; growth synchronises). */
