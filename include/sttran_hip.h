@@ -302,6 +302,20 @@ int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32
                            int32_t num_seq, int32_t max_len, float* out, int64_t tokens,
                            int32_t dim, int32_t nhead, void* stream);
 
+/* DSG-DETR class sequences as the forward builds them on the device (lib/dsg_detr.py:545-555; csrc/kernels_front.hip
+ * dsg_layout_kernel): clip_start [num_clips + 1] = pair range of every clip; outputs dec_off / dec_len
+ * [num_clips * num_classes] (slot = clip * num_classes + class), dec_src (token -> pair), need (token -> position index,
+ * handed out by position like the reference), out_src (pair -> num_pairs + token), each [num_pairs]; scratch4p
+ * [4 * num_pairs] ints; err_flag: bit 0 = index out of range, bit 1 = position index >= pe_rows.  All device pointers. */
+int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int64_t num_boxes, const int32_t* clip_start,
+                            int32_t num_clips, int32_t num_classes, int64_t num_pairs, int32_t pe_rows, int32_t* dec_off,
+                            int32_t* dec_len, int32_t* dec_src, int32_t* need, int32_t* out_src, int32_t* scratch4p,
+                            int32_t* err_flag, void* stream);
+/* sttran_debug_attention for sequences whose lengths only the device knows: len_bound >= every seq_len[i]; one launch per
+ * length class ((0,48], (48,80], (80,len_bound]), empty slots allowed. */
+int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
+                                   int32_t len_bound, float* out, int32_t dim, int32_t nhead, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,11 @@ SYMBOLS = [
                                          C.c_void_p]),
     ("sttran_debug_attention", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    ("sttran_debug_dsg_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    ("sttran_debug_attention_classes", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_int32, C.c_int32, C.c_void_p]),
 ]
 
 _lib = None

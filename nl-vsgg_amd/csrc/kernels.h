@@ -78,6 +78,12 @@ hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float
 hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
                              int P, int K, float* slab);
 
+// DSG-DETR class sequences built on the device (lib/dsg_detr.py:545-555): clip_start [num_clips + 1] pair ranges;
+// dec_off / dec_len [num_clips * NC], dec_src / need / out_src [P], scratch4p [4 P] ints; err_flag bits 0 / 1
+hipError_t launch_dsg_layout(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int B, const int* clip_start,
+                             int num_clips, int NC, int P, int pe_rows, int* dec_off, int* dec_len, int* dec_src, int* need,
+                             int* out_src, int* scratch4p, int* err_flag);
+
 // Recall@K matching of one clip against its packed ground truth (lib/evaluation_recall.py:397-465,630-773):
 // flags[g][metric*3 + k] = ground-truth relation g is hit within the first {10,20,50} predictions of
 // metric {with constraint, no constraint, semi constraint}.  status: bit 0 = a frame has too many pairs,
@@ -102,6 +108,9 @@ hipError_t launch_layernorm(hipStream_t s, const float* x, int64_t ldx, const fl
 // qkv rows are 3*dim floats apart, out rows ldo floats apart
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead);
+// the lengths are only known on the device (len_bound >= every one of them): one launch per length class, no read-back
+hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
+                                    int len_bound, float* out, int64_t ldo, int dim, int nhead);
 constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel accepts
 hipError_t launch_gather_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, float* dst, int64_t ldd,
                               int64_t rows, int dim);

@@ -42,11 +42,11 @@ __device__ __forceinline__ void stage_head_rows(float* dst, const float* __restr
 
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
-                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp) {
+                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp, int len_lo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
   const int L = seq_len[s];
-  if (q0 >= L) return;
+  if (q0 >= L || L <= len_lo) return;           // len_lo: shorter sequences belong to another launch (launch_attention_classes)
   const int base = seq_off[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ps = skp + 4;                       // score row stride
@@ -190,13 +190,13 @@ template <int CHUNK, int VW, int MAXROWS, int MINWG>
 __global__ void __launch_bounds__(256, MINWG)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
                        const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
-                       int64_t ldo, int dim, int hd, float scale, int l16max) {
+                       int64_t ldo, int dim, int hd, float scale, int l16max, int len_lo, int len_hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kMaxQ = MAXROWS / 16;                   // query (and key) tiles of 16 rows
   constexpr int TPW = (kMaxQ * kMaxQ + 3) / 4;          // score tiles per wave
   const int s = blockIdx.y, h = blockIdx.x;
   const int L = seq_len[s];
-  if (L <= 0) return;
+  if (L <= len_lo || L > len_hi) return;                // (len_lo, len_hi]: this launch's length class; len_lo >= 0
   const int qb = q_begin ? q_begin[s] : 0;
   const int Lq = L - qb;
   if (Lq <= 0) return;
@@ -346,6 +346,9 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   }
 }
 
+// dynamic-LDS limits already raised per device, shared by both launchers (a second set of marks could LOWER a limit)
+static DeviceMarks g_attn_marks[2], g_attn_marks_long;
+
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || max_len <= 0) return hipSuccess;
@@ -358,24 +361,62 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
     const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
     const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
-    static DeviceMarks marks[2];
     auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    hipError_t e = marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    hipError_t e = g_attn_marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, ldo, dim,
-                       hd, scale, l16);
+                       hd, scale, l16, 0, 1 << 30);
     return hipGetLastError();
   }
   // the long-sequence kernel computes every query row: q_begin is an optimisation hint only (rows before
   // it are never read by the caller), so it is simply not used here
   const int skp = (max_len + 31) / 32 * 32;
   const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
-  static DeviceMarks marks_long;
-  hipError_t e = marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
+  hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
   if (e != hipSuccess) return e;
   dim3 grid((max_len + 31) / 32, nhead, num_seq);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp, 0);
   return hipGetLastError();
+}
+
+// The same attention when the host does NOT know the sequence lengths (DSG-DETR's class sequences are built on the
+// device): `len_bound` >= every length.  One launch per length class the bound allows -- (0, 48] and (48, 80] on the two
+// short-sequence variants, (80, bound] on the general kernel --, each over all `num_seq` slots; a workgroup whose
+// sequence is empty or belongs to another class returns at once.  No read-back, capturable.
+hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
+                                    int len_bound, float* out, int64_t ldo, int dim, int nhead) {
+  if (num_seq <= 0 || len_bound <= 0) return hipSuccess;
+  const int hd = dim / nhead;
+  if (hd > kHdPad - 2 || (hd & 1) || len_bound > kAttnMaxKeys) return hipErrorInvalidValue;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int edges[3] = {0, 48, kAttnShortMax};
+  for (int v = 0; v < 2; ++v) {
+    if (len_bound <= edges[v]) break;
+    const bool small = v == 0;
+    const int hi = v == 0 ? 48 : kAttnShortMax;
+    const int l16 = ((std::min(len_bound, hi) + 15) & ~15);
+    const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
+    const int region = std::max(2 * l16 * cs, l16 * vs);
+    const int lds = (region + l16 * (l16 + 4)) * 4;
+    auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
+    hipError_t e = g_attn_marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, (const int*)nullptr, out, ldo, dim,
+                       hd, scale, l16, edges[v], hi);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (len_bound > kAttnShortMax) {
+    const int skp = (len_bound + 31) / 32 * 32;
+    const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
+    hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((len_bound + 31) / 32, nhead, num_seq);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp,
+                       kAttnShortMax);
+    return hipGetLastError();
+  }
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -145,4 +145,86 @@ hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float*
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// DSG-DETR class sequences on the device (lib/dsg_detr.py:545-555), one workgroup per clip.
+//   sequence slot  = clip * NC + class (empty slots have length 0)            -> dec_off / dec_len
+//   token order    = the clip's pairs, stably grouped by the class of their object box -> dec_src (token -> pair),
+//                    out_src (pair -> P + token)
+//   position index = handed out BY POSITION like the reference does (`[0]*count_0 + [1]*count_1 + ...` over the sorted
+//                    unique subject boxes): token i of a sequence gets the dense rank of the i-th SMALLEST subject -> need
+// Quadratic in the pairs of a clip (rank by counting), which is a few thousand at most; no host read-back.
+// err_flag: bit 0 = pair_idx / labels out of range (clamped), bit 1 = more position indices than PE rows (clamped).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restrict__ labels, int B, const int* __restrict__ clip_start,
+                  int NC, int P, int pe_rows, int* __restrict__ dec_off, int* __restrict__ dec_len, int* __restrict__ dec_src,
+                  int* __restrict__ need, int* __restrict__ out_src, int* cls_of_pair, int* subj_of_pair, int* subj_of_tok,
+                  int* first_of_tok, int* err_flag) {
+  __shared__ int hist[64], off[64];
+  const int c = blockIdx.x, s = clip_start[c], n = clip_start[c + 1] - s, tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    int64_t sj = pair_idx[2 * (int64_t)(s + i)], ob = pair_idx[2 * (int64_t)(s + i) + 1];
+    bool bad = sj < 0 || sj >= B || ob < 0 || ob >= B;
+    sj = sj < 0 ? 0 : (sj >= B ? B - 1 : sj);
+    ob = ob < 0 ? 0 : (ob >= B ? B - 1 : ob);
+    int64_t lab = labels[ob];
+    bad |= lab < 0 || lab >= NC;
+    lab = lab < 0 ? 0 : (lab >= NC ? NC - 1 : lab);
+    if (bad) atomicOr(err_flag, 1);
+    cls_of_pair[s + i] = (int)lab;
+    subj_of_pair[s + i] = (int)sj;
+    atomicAdd(&hist[lab], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int k = 0; k < NC; ++k) { off[k] = a; a += hist[k]; }
+  }
+  __syncthreads();
+  if (tid < NC) { dec_off[c * NC + tid] = s + off[tid]; dec_len[c * NC + tid] = hist[tid]; }
+  // stable position of pair i inside its class: the pairs before it with the same class
+  for (int i = tid; i < n; i += 256) {
+    const int ci = cls_of_pair[s + i];
+    int r = 0;
+    for (int j = 0; j < i; ++j) r += cls_of_pair[s + j] == ci;
+    const int tok = s + off[ci] + r;
+    dec_src[tok] = s + i;
+    out_src[s + i] = P + tok;
+    subj_of_tok[tok] = subj_of_pair[s + i];
+  }
+  __syncthreads();
+  // first occurrence of its subject inside the sequence?
+  for (int i = tid; i < n; i += 256) {
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], sv = subj_of_tok[t];
+    int f = 1;
+    for (int k = o; k < t; ++k) f &= subj_of_tok[k] != sv;
+    first_of_tok[t] = f;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], len = hist[ci], sv = subj_of_tok[t];
+    int r = 0, d = 0;                       // r = position of this token's subject in the sorted sequence (stable), d = its dense rank
+    for (int k = o; k < o + len; ++k) {
+      const int sk = subj_of_tok[k];
+      r += (sk < sv) || (sk == sv && k < t);
+      d += (sk < sv) && first_of_tok[k];
+    }
+    if (d >= pe_rows) { d = pe_rows - 1; atomicOr(err_flag, 2); }
+    need[o + r] = d;
+  }
+}
+
+hipError_t launch_dsg_layout(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int B, const int* clip_start,
+                             int num_clips, int NC, int P, int pe_rows, int* dec_off, int* dec_len, int* dec_src, int* need,
+                             int* out_src, int* scratch4p, int* err_flag) {
+  if (num_clips <= 0 || P <= 0) return hipSuccess;
+  if (NC > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dsg_layout_kernel, dim3(num_clips), dim3(256), 0, s, pair_idx, labels, B, clip_start, NC, P, pe_rows,
+                     dec_off, dec_len, dec_src, need, out_src, scratch4p, scratch4p + P, scratch4p + 2 * (int64_t)P,
+                     scratch4p + 3 * (int64_t)P, err_flag);
+  return hipGetLastError();
+}
+
 }  // namespace sttran

@@ -83,6 +83,7 @@ struct SttranHandle {
   // workspace
   int64_t capP = 0, capB = 0;
   DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
+  DevBuf dsg;                   // DSG-DETR: class-sequence tables built on the device (launch_dsg_layout)
   int* err_flag = nullptr;
   // index-map staging (pinned) + cache of the last layout
   static constexpr int kStages = 4;
@@ -99,6 +100,9 @@ struct SttranHandle {
     size_t o_enc_off = 0, o_enc_len = 0, o_dec_off = 0, o_dec_len = 0, o_dec_src = 0, o_out_src = 0, o_slot = 0;
     size_t o_need = 0, o_qbegin = 0, o_tok0 = 0, o_tok1 = 0;
     size_t total_ints = 0;
+    size_t o_clip_start = 0;      // DSG-DETR device layout: pair range of every clip [num_clips + 1]
+    int num_clips = 0;
+    bool dsg_device = false;      // the class sequences of this layout are built on the device
   } lay;
   // profiling
   bool prof_on = false;
@@ -295,8 +299,9 @@ EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu = 0) {
 // One post-norm encoder layer over ragged sequences (lib/transformer.py:20-30; also the stock
 // nn.TransformerEncoderLayer of lib/dsg_detr.py:502-506 -- same sub-module names):
 //   h = LN1(x + MHA(x,x,x));  out = LN2(h + W2 relu(W1 h + b1) + b2)
+// len_on_device: `maxlen` is only an upper bound of the sequence lengths (they were computed on the device)
 int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, const float* xin, float* xout, int M,
-                      const int* seq_off, const int* seq_len, int nseq, int maxlen) {
+                      const int* seq_off, const int* seq_len, int nseq, int maxlen, bool len_on_device = false) {
   const SttranConfig& c = h->cfg;
   const int D = c.embed_dim, F = c.ffn_dim;
   const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (xin / xout included)
@@ -307,7 +312,8 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
                        epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
   {
     ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * M * maxlen * D, 4.0 * M * 4 * D, "attention", M, maxlen, D);
-    HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, LD, D, c.nhead));
+    if (len_on_device) HIPCK(launch_attention_classes(s, QKV, seq_off, seq_len, nseq, maxlen, ATT, LD, D, c.nhead));
+    else HIPCK(launch_attention(s, QKV, seq_off, seq_len, nullptr, nseq, maxlen, ATT, LD, D, c.nhead));
   }
   EpiLinear eo = epi_plain(Y, LD, W(h, p + ".self_attn.out_proj.bias"));
   eo.res = xin; eo.ldres = LD;
@@ -481,6 +487,38 @@ void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int3
   L.total_ints = buf.size();
 }
 
+// DSG-DETR, device form: only what the host knows goes through the index buffer -- the spatial sequences (frames) and the
+// pair range of every clip; the class sequences are built by launch_dsg_layout from labels / pair_idx where they live.
+// n_dec_seq = one slot per (clip, class), max_dec = the largest clip (an upper bound of every class sequence).
+void build_layout_dsg_static(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P, int NC,
+                             std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+  std::vector<int32_t> enc_off, enc_len, clip_start;
+  L = SttranHandle::Layout();
+  int64_t o = 0;
+  size_t t = 0;
+  for (size_t c = 0; c < clips.size(); ++c) {
+    clip_start.push_back((int32_t)o);
+    const int64_t o0 = o;
+    for (int f = 0; f < clips[c]; ++f, ++t) {
+      if (counts[t] > 0) { enc_off.push_back((int32_t)o); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
+      o += counts[t];
+    }
+    L.max_dec = std::max<int>(L.max_dec, (int)(o - o0));
+  }
+  clip_start.push_back((int32_t)o);
+  L.n_enc_seq = (int)enc_off.size();
+  L.num_clips = (int)clips.size();
+  L.n_dec_seq = L.num_clips * NC;
+  L.n_dec_tok = P;
+  L.n_need = P;
+  L.dsg_device = true;
+  buf.clear();
+  auto put = [&](const std::vector<int32_t>& v) { size_t off = buf.size(); buf.insert(buf.end(), v.begin(), v.end()); return off; };
+  L.o_enc_off = put(enc_off); L.o_enc_len = put(enc_len);
+  L.o_clip_start = put(clip_start);
+  L.total_ints = buf.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -525,7 +563,7 @@ void sttran_destroy(SttranHandle* h) {
   }
   if (h->w4_planes) hipFree(h->w4_planes);
   for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
-                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf})
+                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf, &h->dsg})
     b->release();
   for (int i = 0; i < SttranHandle::kStages; ++i) {
     if (h->stage[i]) hipHostFree(h->stage[i]);
@@ -819,10 +857,26 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
 
   // ---- index maps (cached while the layout repeats) -----------------------------------------
   const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
-  if (is_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips)) {
+  // DSG-DETR builds its class sequences on the device (no read-back, cacheable, capturable) whenever every clip is small
+  // enough for its pair count to serve as the attention's length bound; larger clips (64x36: 2 240 pairs) and
+  // STTRAN_DSG_HOST_LAYOUT=1 take the host builder, which reads labels / pair_idx back on every call.
+  static const bool dsg_host_env = getenv("STTRAN_DSG_HOST_LAYOUT") && atoi(getenv("STTRAN_DSG_HOST_LAYOUT")) != 0;
+  bool dsg_dev = is_dsg && !dsg_host_env;
+  if (dsg_dev) {
+    size_t t = 0;
+    for (size_t ci = 0; ci < clips.size() && dsg_dev; ++ci) {
+      int64_t n = 0;
+      for (int f = 0; f < clips[ci]; ++f, ++t) n += counts[t];
+      if (n > kAttnMaxKeys) dsg_dev = false;
+    }
+  }
+  const bool host_dsg = is_dsg && !dsg_dev;
+  if (host_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips && h->lay.dsg_device == dsg_dev)) {
     std::vector<int32_t> buf;
     h->cached_P = -1;      // h->lay is about to change: the cache only becomes valid again once the upload is enqueued
-    if (is_dsg) {
+    if (dsg_dev) {
+      build_layout_dsg_static(counts, clips, P, c.num_obj_classes, buf, h->lay);
+    } else if (is_dsg) {
       // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
       // second model on the shared kernels, not the latency path
       std::vector<int64_t> hp((size_t)P * 2), hl((size_t)B);
@@ -852,7 +906,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
     HIPCK(hipMemcpyAsync(h->idx.p, h->stage[k], buf.size() * 4, hipMemcpyHostToDevice, s));
     HIPCK(hipEventRecord(h->stage_ev[k], s));
-    h->cached_P = is_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
+    h->cached_P = host_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
   }
   const SttranHandle::Layout& L = h->lay;
   const int32_t* ib = h->idx.as<int32_t>();
@@ -862,6 +916,17 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   const uint8_t* slot = reinterpret_cast<const uint8_t*>(ib + L.o_slot);
   const int* need = ib + L.o_need; const int* qbegin = ib + L.o_qbegin;
   const int* tok0 = ib + L.o_tok0; const int* tok1 = ib + L.o_tok1;
+  if (L.dsg_device) {
+    // class sequences from labels[pair_idx[:, 1]] where they live: [dec_off | dec_len] per (clip, class) slot, then
+    // dec_src, need, out_src per token / pair, then 4 P ints of scratch
+    const int64_t Kseq = L.n_dec_seq;
+    HIPCK(h->dsg.ensure((size_t)(2 * Kseq + 7 * P + 64) * 4));
+    int* d = h->dsg.as<int32_t>();
+    HIPCK(launch_dsg_layout(s, in->pair_idx, in->labels, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P,
+                            400, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, d + 2 * Kseq + 3 * P,
+                            h->err_flag));
+    dec_off = d; dec_len = d + Kseq; dec_src = d + 2 * Kseq; need = d + 2 * Kseq + P; out_src = d + 2 * Kseq + 2 * P;
+  }
   int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
   int* obj_idx = subj_idx + h->capP;
 
@@ -969,7 +1034,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     for (int i = 0; i < 3; ++i) {
       float* gout = (i == 2) ? UDEC : (i == 0 ? E : G);
       if ((rc = run_encoder_layer(h, s, "global_transformer.layers." + std::to_string(i), gin, gout, (int)P, dec_off,
-                                  dec_len, L.n_dec_seq, L.max_dec))) return rc;
+                                  dec_len, L.n_dec_seq, L.max_dec, L.dsg_device))) return rc;
       gin = gout;
     }
   } else
@@ -1064,7 +1129,8 @@ int sttran_sync_check(SttranHandle* h, void* stream) {
   HIPCK(hipMemcpy(&flag, h->err_flag, 4, hipMemcpyDeviceToHost));
   if (flag) {
     HIPCK(hipMemset(h->err_flag, 0, 4));
-    return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx or labels out of range (values were clamped)");
+    if (flag & 1) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx or labels out of range (values were clamped)");
+    return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence (position index clamped)");
   }
   return STTRAN_OK;
 }
@@ -1238,6 +1304,26 @@ int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32
   if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
   return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, nullptr, num_seq, max_len, out, dim,
                           dim, nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+// test hook: the DSG-DETR class-sequence tables exactly as the forward builds them on the device, and (len_bound > 0)
+// the attention over sequences whose lengths only the device knows
+int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int64_t num_boxes, const int32_t* clip_start,
+                            int32_t num_clips, int32_t num_classes, int64_t num_pairs, int32_t pe_rows, int32_t* dec_off,
+                            int32_t* dec_len, int32_t* dec_src, int32_t* need, int32_t* out_src, int32_t* scratch4p,
+                            int32_t* err_flag, void* stream) {
+  if (!pair_idx || !labels || !clip_start || !dec_off || !dec_len || !dec_src || !need || !out_src || !scratch4p || !err_flag)
+    return STTRAN_ERR_INVALID;
+  return launch_dsg_layout(reinterpret_cast<hipStream_t>(stream), pair_idx, labels, (int)num_boxes, clip_start, num_clips,
+                           num_classes, (int)num_pairs, pe_rows, dec_off, dec_len, dec_src, need, out_src, scratch4p,
+                           err_flag) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
+                                   int32_t len_bound, float* out, int32_t dim, int32_t nhead, void* stream) {
+  if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
+  return launch_attention_classes(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, num_seq, len_bound, out, dim,
+                                  dim, nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
 }  // extern "C"

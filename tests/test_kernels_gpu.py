@@ -267,3 +267,106 @@ def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
     e1 = (C1.double() - ref).abs().max().item()
     assert torch.isfinite(C3).all()
     assert e3 <= 2.0 * e1 + 1e-6, (e3, e1)
+
+
+# ---- DSG-DETR on the device: class sequences (lib/dsg_detr.py:545-555) and attention over lengths the host never sees ---
+def _dsg_layout_ref(pair_idx, labels, clip_start, NC):
+    """numpy restatement in the reference's own terms: per clip, per class present, the pairs in pair order; position
+    indices `[0]*count_0 + [1]*count_1 + ...` over the sorted unique subjects (lib/dsg_detr.py:551-554)"""
+    P = pair_idx.shape[0]
+    nclips = len(clip_start) - 1
+    dec_off = np.zeros(nclips * NC, np.int32); dec_len = np.zeros(nclips * NC, np.int32)
+    dec_src = np.zeros(P, np.int32); need = np.zeros(P, np.int32); out_src = np.zeros(P, np.int32)
+    tok = 0
+    for c in range(nclips):
+        s, e = clip_start[c], clip_start[c + 1]
+        cls = labels[pair_idx[s:e, 1]]
+        for k in range(NC):
+            idx = np.nonzero(cls == k)[0] + s
+            dec_off[c * NC + k] = tok; dec_len[c * NC + k] = len(idx)
+            if len(idx):
+                _, cnt = np.unique(pair_idx[idx, 0], return_counts=True)
+                dec_src[tok:tok + len(idx)] = idx
+                need[tok:tok + len(idx)] = np.repeat(np.arange(len(cnt)), cnt)
+                out_src[idx] = P + tok + np.arange(len(idx))
+                tok += len(idx)
+    return dec_off, dec_len, dec_src, need, out_src
+
+
+@pytest.mark.parametrize("seed,clip_pairs,B", [(1, [7], 12), (2, [30, 1, 55], 40), (3, [200, 3], 64), (4, [1, 1, 1, 1], 5),
+                                               (5, [480], 90), (6, [0, 9, 0, 4], 10)])
+def test_dsg_layout_on_device(lib, seed, clip_pairs, B):
+    """random pair lists (subjects in ANY order, repeated subjects, classes 0..36, an empty clip) against the restatement"""
+    rng = np.random.default_rng(seed)
+    NC, P = 37, int(sum(clip_pairs))
+    pair = np.stack([rng.integers(0, B, P), rng.integers(0, B, P)], axis=1).astype(np.int64)
+    labels = rng.integers(0, NC, B).astype(np.int64)
+    if seed == 5:
+        labels[:] = 7                                                    # one 480-token sequence, few distinct subjects
+    clip_start = np.concatenate([[0], np.cumsum(clip_pairs)]).astype(np.int32)
+    K = (len(clip_pairs)) * NC
+    dev = lambda a: torch.from_numpy(a).cuda()
+    d_pair, d_lab, d_cs = dev(pair), dev(labels), dev(clip_start)
+    outs = [torch.full((n,), -7, dtype=torch.int32, device="cuda") for n in (K, K, P, P, P)]
+    scratch = torch.zeros(4 * P, dtype=torch.int32, device="cuda")
+    err = torch.zeros(16, dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_dsg_layout(_p(d_pair), _p(d_lab), B, _p(d_cs), len(clip_pairs), NC, P, 400, *[_p(o) for o in outs],
+                                       _p(scratch), _p(err), None) == 0
+    torch.cuda.synchronize()
+    ref = _dsg_layout_ref(pair, labels, clip_start, NC)
+    for name, o, r in zip(("dec_off", "dec_len", "dec_src", "need", "out_src"), outs, ref):
+        got = o.cpu().numpy()
+        if name == "dec_off":                                            # the offset of an empty slot is arbitrary
+            m = ref[1] > 0
+            np.testing.assert_array_equal(got[m], r[m], err_msg=name)
+        else:
+            np.testing.assert_array_equal(got, r, err_msg=name)
+    assert int(err[0]) == 0
+
+
+def test_dsg_layout_flags_bad_indices_and_long_sequences(lib):
+    NC, B = 37, 8
+    pair = np.array([[0, 1], [2, 99], [3, 4]], np.int64)                 # an object box out of range
+    labels = np.array([1, 5, 1, 1, 40, 1, 1, 1], np.int64)               # ... and a label out of range
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for n in (NC, NC, 3, 3, 3)]
+    err = torch.zeros(16, dtype=torch.int32, device="cuda")
+    cs = torch.tensor([0, 3], dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_dsg_layout(_p(torch.from_numpy(pair).cuda()), _p(torch.from_numpy(labels).cuda()), B, _p(cs), 1, NC, 3,
+                                       400, *[_p(o) for o in outs], _p(torch.zeros(12, dtype=torch.int32, device="cuda")),
+                                       _p(err), None) == 0
+    torch.cuda.synchronize()
+    assert int(err[0]) & 1
+    # 5 distinct subjects in one class but only 3 position rows: clamped and flagged
+    pair = np.stack([np.arange(5), np.full(5, 6)], axis=1).astype(np.int64)
+    labels = np.full(8, 3, np.int64)
+    outs = [torch.zeros(n, dtype=torch.int32, device="cuda") for n in (NC, NC, 5, 5, 5)]
+    err.zero_()
+    cs = torch.tensor([0, 5], dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_dsg_layout(_p(torch.from_numpy(pair).cuda()), _p(torch.from_numpy(labels).cuda()), B, _p(cs), 1, NC, 5,
+                                       3, *[_p(o) for o in outs], _p(torch.zeros(20, dtype=torch.int32, device="cuda")),
+                                       _p(err), None) == 0
+    torch.cuda.synchronize()
+    assert int(err[0]) == 2 and outs[3].cpu().tolist() == [0, 1, 2, 2, 2]
+
+
+@pytest.mark.parametrize("lens,bound", [([5, 0, 17, 48, 49, 0, 80, 3], 80), ([30, 81, 0, 200, 12, 64], 230), ([1, 2, 3], 40),
+                                        ([0, 0, 0], 100), ([48, 16], 48)])
+def test_attention_over_device_side_lengths(lib, lens, bound):
+    """every length class in one call, empty slots included; rows of no sequence stay untouched"""
+    dim, nhead = 1936, 8
+    g = torch.Generator(device="cuda").manual_seed(sum(lens) + bound)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    tokens = max(int(sum(lens)), 1)
+    qkv = torch.randn(tokens, 3 * dim, device="cuda", generator=g)
+    out = torch.full((tokens, dim), float("nan"), device="cuda")
+    so = torch.from_numpy(offs).cuda()
+    sl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_attention_classes(_p(qkv), _p(so), _p(sl), len(lens), bound, _p(out), dim, nhead, None) == 0
+    torch.cuda.synchronize()
+    if sum(lens) == 0:
+        assert torch.isnan(out).all()
+        return
+    keep = [i for i, l in enumerate(lens) if l > 0]
+    ref = _attn_ref(qkv, [int(offs[i]) for i in keep], [lens[i] for i in keep], dim, nhead)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 2e-5

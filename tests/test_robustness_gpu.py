@@ -179,3 +179,47 @@ def test_out_of_range_index_is_an_index_error(weights):
     with pytest.raises(IndexError):
         m.sync_check()                                      # ... and reported when asked
     m.sync_check()                                          # the flag is cleared by the report
+
+
+def test_dsg_detr_is_enqueue_only_and_capturable():
+    """DSG-DETR builds its class sequences on the device (clips of <= 480 pairs): with check_indices off the forward only
+    enqueues -- it can be captured into a HIP graph and replayed on new labels --, and an out-of-range label is reported
+    the way STTran reports it (clamped, flagged, IndexError at the next check)"""
+    from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
+    sd = syn.make_dsg_detr_state_dict(7)
+    m = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    e = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) and k != "frame_counts" else v)
+         for k, v in syn.make_entry(77, [3, 2, 4, 1], mode="sgdet", im_idx_dtype=np.int64).items()}
+    keep = {k: e[k].clone() for k in ("labels", "distribution")}
+    want = {k: v.clone() for k, v in m(dict(e)).items() if k.endswith("_distribution")}
+    m.check_indices = False
+    static = dict(e)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(dict(static)); m(dict(static))
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(dict(static))
+    g.replay()
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(out[k], want[k]), k
+    # new labels in the captured input tensor: the replay regroups the pairs on the device
+    perm = torch.randperm(36, device="cuda") + 1
+    static["labels"].copy_(torch.where(keep["labels"] == 1, keep["labels"], perm[(keep["labels"] - 1).clamp(min=0)]))
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = dict(e); fresh["labels"] = static["labels"].clone(); fresh["distribution"] = keep["distribution"].clone()
+    m2 = m(dict(fresh))
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(out[k], m2[k]), k
+    assert not torch.equal(out["attention_distribution"], want["attention_distribution"])
+    # out-of-range label: clamped + flagged, raised by the check
+    m.check_indices = True
+    bad = dict(e); bad["labels"] = keep["labels"].clone(); bad["labels"][2] = 99; bad["distribution"] = keep["distribution"].clone()
+    with pytest.raises(IndexError):
+        m(bad)
