@@ -496,9 +496,6 @@ def main():
 
     env = Env(args)
     rank, world, device = env.rank, env.world, env.device
-    if args.graph and args.model == "dsgdetr" and SHAPES[args.workload][0] * (SHAPES[args.workload][1] - 1) > 480:
-        raise SystemExit("--graph: DSG-DETR builds its class sequences on the device only for clips of at most 480 pairs; "
-                         "larger clips (64x36) read labels / pair_idx back on every call, which cannot be captured")
     T, N, cps_default = SHAPES[args.workload]
     cps = args.clips_per_step or cps_default
     if args.model == "dsgdetr":

@@ -79,10 +79,11 @@ hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, cons
                              int P, int K, float* slab);
 
 // DSG-DETR class sequences built on the device (lib/dsg_detr.py:545-555): clip_start [num_clips + 1] pair ranges;
-// dec_off / dec_len [num_clips * NC], dec_src / need / out_src [P], scratch4p [4 P] ints; err_flag bits 0 / 1
+// dec_off / dec_len [num_clips * NC], dec_src / need / out_src [P], scratch4p [4 P] ints; err_flag bits 0 / 1;
+// max_clip_pairs (0 = unknown) lets the kernel keep its per-token tables in LDS
 hipError_t launch_dsg_layout(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int B, const int* clip_start,
-                             int num_clips, int NC, int P, int pe_rows, int* dec_off, int* dec_len, int* dec_src, int* need,
-                             int* out_src, int* scratch4p, int* err_flag);
+                             int num_clips, int NC, int P, int pe_rows, int max_len, int* dec_off, int* dec_len, int* dec_src,
+                             int* need, int* out_src, int* scratch4p, int* err_flag, int max_clip_pairs);
 
 // Recall@K matching of one clip against its packed ground truth (lib/evaluation_recall.py:397-465,630-773):
 // flags[g][metric*3 + k] = ground-truth relation g is hit within the first {10,20,50} predictions of

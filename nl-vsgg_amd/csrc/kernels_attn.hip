@@ -42,11 +42,13 @@ __device__ __forceinline__ void stage_head_rows(float* dst, const float* __restr
 
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
-                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp, int len_lo) {
+                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp, int len_lo, int len_hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
   const int L = seq_len[s];
-  if (q0 >= L || L <= len_lo) return;           // len_lo: shorter sequences belong to another launch (launch_attention_classes)
+  // (len_lo, len_hi]: shorter sequences belong to another launch (launch_attention_classes); longer ones than the LDS was
+  // sized for are skipped (the layout kernel has flagged them)
+  if (q0 >= L || L <= len_lo || L > len_hi) return;
   const int base = seq_off[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ps = skp + 4;                       // score row stride
@@ -375,7 +377,7 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
   hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
   if (e != hipSuccess) return e;
   dim3 grid((max_len + 31) / 32, nhead, num_seq);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp, 0);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp, 0, 1 << 30);
   return hipGetLastError();
 }
 
@@ -387,7 +389,8 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
                                     int len_bound, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || len_bound <= 0) return hipSuccess;
   const int hd = dim / nhead;
-  if (hd > kHdPad - 2 || (hd & 1) || len_bound > kAttnMaxKeys) return hipErrorInvalidValue;
+  if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
+  if (len_bound > kAttnMaxKeys) len_bound = kAttnMaxKeys;      // longer sequences are skipped (and flagged by their producer)
   const float scale = 1.0f / sqrtf((float)hd);
   const int edges[3] = {0, 48, kAttnShortMax};
   for (int v = 0; v < 2; ++v) {
@@ -413,7 +416,7 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     if (e != hipSuccess) return e;
     dim3 grid((len_bound + 31) / 32, nhead, num_seq);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp,
-                       kAttnShortMax);
+                       kAttnShortMax, len_bound);
     return hipGetLastError();
   }
   return hipSuccess;

@@ -153,15 +153,22 @@ hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float*
 //   position index = handed out BY POSITION like the reference does (`[0]*count_0 + [1]*count_1 + ...` over the sorted
 //                    unique subject boxes): token i of a sequence gets the dense rank of the i-th SMALLEST subject -> need
 // Quadratic in the pairs of a clip (rank by counting), which is a few thousand at most; no host read-back.
-// err_flag: bit 0 = pair_idx / labels out of range (clamped), bit 1 = more position indices than PE rows (clamped).
+// err_flag: bit 0 = pair_idx / labels out of range (clamped), bit 1 = more position indices than PE rows (clamped) or a
+// sequence longer than max_len (the attention's key limit: such a sequence is skipped).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restrict__ labels, int B, const int* __restrict__ clip_start,
-                  int NC, int P, int pe_rows, int* __restrict__ dec_off, int* __restrict__ dec_len, int* __restrict__ dec_src,
+                  int NC, int P, int pe_rows, int max_len, int* __restrict__ dec_off, int* __restrict__ dec_len, int* __restrict__ dec_src,
                   int* __restrict__ need, int* __restrict__ out_src, int* cls_of_pair, int* subj_of_pair, int* subj_of_tok,
-                  int* first_of_tok, int* err_flag) {
+                  int* first_of_tok, int* err_flag, int lds_ints) {
+  // with room in LDS (2 ints per pair of the largest clip) the subject / first-occurrence tables of the clip live there
+  // (rows s .. s+n of the global scratch otherwise): the two passes below read them O(sequence length) times per token
+  extern __shared__ int dyn[];
   __shared__ int hist[64], off[64];
   const int c = blockIdx.x, s = clip_start[c], n = clip_start[c + 1] - s, tid = threadIdx.x;
+  const bool in_lds = 2 * n <= lds_ints;
+  int* subj_t = in_lds ? dyn - s : subj_of_tok;            // indexed by token, like the global tables
+  int* first_t = in_lds ? dyn + n - s : first_of_tok;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -183,33 +190,49 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
     for (int k = 0; k < NC; ++k) { off[k] = a; a += hist[k]; }
   }
   __syncthreads();
-  if (tid < NC) { dec_off[c * NC + tid] = s + off[tid]; dec_len[c * NC + tid] = hist[tid]; }
-  // stable position of pair i inside its class: the pairs before it with the same class
-  for (int i = tid; i < n; i += 256) {
-    const int ci = cls_of_pair[s + i];
-    int r = 0;
-    for (int j = 0; j < i; ++j) r += cls_of_pair[s + j] == ci;
-    const int tok = s + off[ci] + r;
-    dec_src[tok] = s + i;
-    out_src[s + i] = P + tok;
-    subj_of_tok[tok] = subj_of_pair[s + i];
+  if (tid < NC) {
+    dec_off[c * NC + tid] = s + off[tid]; dec_len[c * NC + tid] = hist[tid];
+    if (hist[tid] > max_len) atomicOr(err_flag, 2);      // the attention skips such a sequence
   }
+  // stable position of pair i inside its class = the pairs before it with the same class: the clip is walked in chunks
+  // of 256 pairs, `placed` counts per class what the earlier chunks held, the rank inside the chunk is counted from an
+  // LDS copy of the chunk's classes (every lane reads the same byte: a broadcast)
+  __shared__ int placed[64];
+  __shared__ unsigned char chunk_cls[256];
+  if (tid < 64) placed[tid] = 0;
   __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    const int ci = i < n ? cls_of_pair[s + i] : 255;
+    chunk_cls[tid] = (unsigned char)ci;
+    __syncthreads();
+    if (i < n) {
+      int r = placed[ci];
+      for (int j = 0; j < tid; ++j) r += chunk_cls[j] == ci;
+      const int tok = s + off[ci] + r;
+      dec_src[tok] = s + i;
+      out_src[s + i] = P + tok;
+      subj_t[tok] = subj_of_pair[s + i];
+    }
+    __syncthreads();
+    if (i < n) atomicAdd(&placed[ci], 1);
+    __syncthreads();
+  }
   // first occurrence of its subject inside the sequence?
   for (int i = tid; i < n; i += 256) {
-    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], sv = subj_of_tok[t];
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], sv = subj_t[t];
     int f = 1;
-    for (int k = o; k < t; ++k) f &= subj_of_tok[k] != sv;
-    first_of_tok[t] = f;
+    for (int k = o; k < t; ++k) f &= subj_t[k] != sv;
+    first_t[t] = f;
   }
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
-    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], len = hist[ci], sv = subj_of_tok[t];
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], len = hist[ci], sv = subj_t[t];
     int r = 0, d = 0;                       // r = position of this token's subject in the sorted sequence (stable), d = its dense rank
     for (int k = o; k < o + len; ++k) {
-      const int sk = subj_of_tok[k];
+      const int sk = subj_t[k];
       r += (sk < sv) || (sk == sv && k < t);
-      d += (sk < sv) && first_of_tok[k];
+      d += (sk < sv) && first_t[k];
     }
     if (d >= pe_rows) { d = pe_rows - 1; atomicOr(err_flag, 2); }
     need[o + r] = d;
@@ -217,13 +240,15 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
 }
 
 hipError_t launch_dsg_layout(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int B, const int* clip_start,
-                             int num_clips, int NC, int P, int pe_rows, int* dec_off, int* dec_len, int* dec_src, int* need,
-                             int* out_src, int* scratch4p, int* err_flag) {
+                             int num_clips, int NC, int P, int pe_rows, int max_len, int* dec_off, int* dec_len, int* dec_src,
+                             int* need, int* out_src, int* scratch4p, int* err_flag, int max_clip_pairs) {
   if (num_clips <= 0 || P <= 0) return hipSuccess;
   if (NC > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dsg_layout_kernel, dim3(num_clips), dim3(256), 0, s, pair_idx, labels, B, clip_start, NC, P, pe_rows,
-                     dec_off, dec_len, dec_src, need, out_src, scratch4p, scratch4p + P, scratch4p + 2 * (int64_t)P,
-                     scratch4p + 3 * (int64_t)P, err_flag);
+  // LDS for the largest clip's two per-token tables when they fit 48 KB (6 144 pairs), none otherwise
+  const int lds_ints = (max_clip_pairs > 0 && max_clip_pairs <= 6144) ? 2 * max_clip_pairs : 0;
+  hipLaunchKernelGGL(dsg_layout_kernel, dim3(num_clips), dim3(256), lds_ints * 4, s, pair_idx, labels, B, clip_start, NC, P, pe_rows,
+                     max_len, dec_off, dec_len, dec_src, need, out_src, scratch4p, scratch4p + P, scratch4p + 2 * (int64_t)P,
+                     scratch4p + 3 * (int64_t)P, err_flag, lds_ints);
   return hipGetLastError();
 }
 

@@ -857,19 +857,10 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
 
   // ---- index maps (cached while the layout repeats) -----------------------------------------
   const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
-  // DSG-DETR builds its class sequences on the device (no read-back, cacheable, capturable) whenever every clip is small
-  // enough for its pair count to serve as the attention's length bound; larger clips (64x36: 2 240 pairs) and
-  // STTRAN_DSG_HOST_LAYOUT=1 take the host builder, which reads labels / pair_idx back on every call.
+  // DSG-DETR builds its class sequences on the device (no read-back, cacheable, capturable); STTRAN_DSG_HOST_LAYOUT=1
+  // takes round 1's host builder instead, which reads labels / pair_idx back on every call (kept for A/B tests).
   static const bool dsg_host_env = getenv("STTRAN_DSG_HOST_LAYOUT") && atoi(getenv("STTRAN_DSG_HOST_LAYOUT")) != 0;
-  bool dsg_dev = is_dsg && !dsg_host_env;
-  if (dsg_dev) {
-    size_t t = 0;
-    for (size_t ci = 0; ci < clips.size() && dsg_dev; ++ci) {
-      int64_t n = 0;
-      for (int f = 0; f < clips[ci]; ++f, ++t) n += counts[t];
-      if (n > kAttnMaxKeys) dsg_dev = false;
-    }
-  }
+  const bool dsg_dev = is_dsg && !dsg_host_env;
   const bool host_dsg = is_dsg && !dsg_dev;
   if (host_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips && h->lay.dsg_device == dsg_dev)) {
     std::vector<int32_t> buf;
@@ -891,7 +882,9 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     } else {
       build_layout(counts, clips, P, buf, h->lay);
     }
-    if (h->lay.max_enc > kAttnMaxKeys || h->lay.max_dec > kAttnMaxKeys)
+    // (device-built class sequences: max_dec is only the largest clip; a sequence over the limit is flagged by the
+    //  layout kernel and reported by sttran_sync_check)
+    if (h->lay.max_enc > kAttnMaxKeys || (!h->lay.dsg_device && h->lay.max_dec > kAttnMaxKeys))
       return fail(h, STTRAN_ERR_LIMIT, "forward: a frame/window exceeds the attention key limit");
     const int k = h->stage_next;
     h->stage_next = (k + 1) % SttranHandle::kStages;
@@ -923,8 +916,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     HIPCK(h->dsg.ensure((size_t)(2 * Kseq + 7 * P + 64) * 4));
     int* d = h->dsg.as<int32_t>();
     HIPCK(launch_dsg_layout(s, in->pair_idx, in->labels, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P,
-                            400, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, d + 2 * Kseq + 3 * P,
-                            h->err_flag));
+                            400, kAttnMaxKeys, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, d + 2 * Kseq + 3 * P,
+                            h->err_flag, L.max_dec));
     dec_off = d; dec_len = d + Kseq; dec_src = d + 2 * Kseq; need = d + 2 * Kseq + P; out_src = d + 2 * Kseq + 2 * P;
   }
   int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
@@ -1130,7 +1123,7 @@ int sttran_sync_check(SttranHandle* h, void* stream) {
   if (flag) {
     HIPCK(hipMemset(h->err_flag, 0, 4));
     if (flag & 1) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx or labels out of range (values were clamped)");
-    return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence (position index clamped)");
+    return fail(h, STTRAN_ERR_LIMIT, "forward: a class sequence has more than 400 frames or exceeds the attention key limit");
   }
   return STTRAN_OK;
 }
@@ -1315,8 +1308,8 @@ int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int6
   if (!pair_idx || !labels || !clip_start || !dec_off || !dec_len || !dec_src || !need || !out_src || !scratch4p || !err_flag)
     return STTRAN_ERR_INVALID;
   return launch_dsg_layout(reinterpret_cast<hipStream_t>(stream), pair_idx, labels, (int)num_boxes, clip_start, num_clips,
-                           num_classes, (int)num_pairs, pe_rows, dec_off, dec_len, dec_src, need, out_src, scratch4p,
-                           err_flag) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+                           num_classes, (int)num_pairs, pe_rows, kAttnMaxKeys, dec_off, dec_len, dec_src, need, out_src, scratch4p,
+                           err_flag, (int)std::min<int64_t>(num_pairs, 6144)) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
 int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
