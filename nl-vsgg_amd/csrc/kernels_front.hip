@@ -167,8 +167,10 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
   __shared__ int hist[64], off[64];
   const int c = blockIdx.x, s = clip_start[c], n = clip_start[c + 1] - s, tid = threadIdx.x;
   const bool in_lds = 2 * n <= lds_ints;
-  int* subj_t = in_lds ? dyn - s : subj_of_tok;            // indexed by token, like the global tables
-  int* first_t = in_lds ? dyn + n - s : first_of_tok;
+  // both tables are indexed by (token - s); no pointer is ever formed outside its buffer (an LDS pointer minus s wraps in
+  // its 32-bit address space and faults once it is used as a flat address)
+  int* subj_t = in_lds ? dyn : subj_of_tok + s;
+  int* first_t = in_lds ? dyn + n : first_of_tok + s;
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
@@ -212,7 +214,7 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
       const int tok = s + off[ci] + r;
       dec_src[tok] = s + i;
       out_src[s + i] = P + tok;
-      subj_t[tok] = subj_of_pair[s + i];
+      subj_t[tok - s] = subj_of_pair[s + i];
     }
     __syncthreads();
     if (i < n) atomicAdd(&placed[ci], 1);
@@ -220,19 +222,19 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
   }
   // first occurrence of its subject inside the sequence?
   for (int i = tid; i < n; i += 256) {
-    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], sv = subj_t[t];
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], sv = subj_t[i];
     int f = 1;
-    for (int k = o; k < t; ++k) f &= subj_t[k] != sv;
-    first_t[t] = f;
+    for (int k = o; k < t; ++k) f &= subj_t[k - s] != sv;
+    first_t[i] = f;
   }
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
-    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], len = hist[ci], sv = subj_t[t];
+    const int t = s + i, ci = cls_of_pair[dec_src[t]], o = s + off[ci], len = hist[ci], sv = subj_t[i];
     int r = 0, d = 0;                       // r = position of this token's subject in the sorted sequence (stable), d = its dense rank
     for (int k = o; k < o + len; ++k) {
-      const int sk = subj_t[k];
+      const int sk = subj_t[k - s];
       r += (sk < sv) || (sk == sv && k < t);
-      d += (sk < sv) && first_t[k];
+      d += (sk < sv) && first_t[k - s];
     }
     if (d >= pe_rows) { d = pe_rows - 1; atomicOr(err_flag, 2); }
     need[o + r] = d;

@@ -294,7 +294,10 @@ def _dsg_layout_ref(pair_idx, labels, clip_start, NC):
 
 
 @pytest.mark.parametrize("seed,clip_pairs,B", [(1, [7], 12), (2, [30, 1, 55], 40), (3, [200, 3], 64), (4, [1, 1, 1, 1], 5),
-                                               (5, [480], 90), (6, [0, 9, 0, 4], 10)])
+                                               (5, [480], 90), (6, [0, 9, 0, 4], 10),
+                                               # many clips: large pair offsets with the per-clip tables in LDS (an LDS pointer
+                                               # moved back by the clip's offset once faulted here), and a clip too big for LDS
+                                               (7, [176] * 64, 500), (8, [7000, 50], 3000)])
 def test_dsg_layout_on_device(lib, seed, clip_pairs, B):
     """random pair lists (subjects in ANY order, repeated subjects, classes 0..36, an empty clip) against the restatement"""
     rng = np.random.default_rng(seed)
