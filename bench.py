@@ -18,6 +18,14 @@ With N > 1 every rank runs its own clips (whole-clip sharding, weak scaling: per
 the aggregate grows ~N x unless host glue or the gather contends) and each step's predictions are
 all-gathered over RCCL inside the timed region by `lib/distributed.py::PredictionGatherer` (the code the
 gloo tests cover): issued asynchronously into a ring of two buffer sets, i.e. under the next forward.
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks ITSELF as fresh child
+processes -- before this process makes any GPU call -- relays rank 0's JSON line and exits non-zero if a
+rank does.  With N > 1 the line's `value` is measured on the 64x36 clip (BASELINE configs[3], the workload
+north_star quotes the scaling target on; 16x12 rides in `workloads`), the line lists the device every rank
+ran on (`devices`: ordinal + PCI bus id, `distinct_devices`), what rank 0 alone reaches on the same per-GPU
+workload while the others idle (`one_rank_alone`), and a STRONG-scaling block (`strong_scaling`: a fixed
+clip set sharded with `assign_clips`, one gather per round, rank 0 scores every clip with the device
+evaluator; per-rank busy time and the LPT imbalance are reported).
 
 One JSON line is printed by rank 0; it carries the roofline of the dominant kernel class (the fp32 MFMA
 GEMM: algorithmic 2*M*N*K FLOPs / HIP-event time, measured in a second, instrumented run of the same K
@@ -31,6 +39,8 @@ one-clip leg, no second workload, no instrumented leg, no CPU baseline): the for
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -74,28 +84,35 @@ def device_clip(T, N, gen, device):
     }
 
 
-def cpu_baseline(T, N, sd, budget_s=24.0):
+def cpu_baseline(T, N, sd, budget_s=24.0, model_kind="sttran", threads=None):
     """The numpy oracle (a port of the reference's CPU path, validated against it by the golden
     tests) timed on this host: one clip per run.  BLAS thread counts 8 / 32 / all cores are tried
-    (small GEMMs oversubscribe a 256-core host) and the fastest setting is reported with its count."""
+    (small GEMMs oversubscribe a 256-core host) and the fastest setting is reported with its count;
+    `threads` pins the count instead (the second clip shape re-uses the winner of the first)."""
     from oracle import sttran_oracle as orc
-    entry = syn.uniform_clip(11, T, N)
+    if model_kind == "dsgdetr":
+        entry = syn.uniform_clip(11, T, N, mode="sgdet")
+        fwd = lambda: orc.dsg_detr_forward(entry, sd)
+    else:
+        entry = syn.uniform_clip(11, T, N)
+        fwd = lambda: orc.sttran_forward(entry, sd)
     try:
         from threadpoolctl import threadpool_limits
     except Exception:                                   # threadpoolctl absent: whatever BLAS defaults to
         threadpool_limits = None
     ncpu = os.cpu_count() or 1
+    tries = [min(int(threads), ncpu)] if threads else sorted({min(8, ncpu), min(32, ncpu), ncpu})
     best = None
-    for nthr in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+    for nthr in tries:
         ctx = threadpool_limits(limits=nthr) if threadpool_limits else None
         try:
             t0 = time.perf_counter()
-            orc.sttran_forward(entry, sd)              # warm-up (BLAS threads, page faults)
+            fwd()                                       # warm-up (BLAS threads, page faults)
             first = time.perf_counter() - t0
             runs = []
-            while sum(runs) + first < budget_s / 3 and len(runs) < 3:
+            while sum(runs) + first < budget_s / len(tries) and len(runs) < 3:
                 t0 = time.perf_counter()
-                orc.sttran_forward(entry, sd)
+                fwd()
                 runs.append(time.perf_counter() - t0)
         finally:
             if ctx is not None:
@@ -104,59 +121,194 @@ def cpu_baseline(T, N, sd, budget_s=24.0):
         if best is None or med < best[0]:
             best = (med, nthr, max(len(runs), 1))
     med, nthr, nruns = best
+    what = "DSG-DETR sgdet" if model_kind == "dsgdetr" else "STTran PredCls"
     return {"value": T / med, "unit": "frames/s", "cores": nthr, "host_cores": ncpu, "kind": "port",
-            "sample": f"{nruns} forward(s) of one {T}x{N} clip, numpy/BLAS fp32 oracle, best of 8/32/{ncpu} BLAS "
-                      f"threads (cores = the thread count of the best run), median {med:.3f} s/clip"}
+            "sample": f"{nruns} forward(s) of one {T}x{N} clip ({what}), numpy/BLAS fp32 oracle, "
+                      + (f"{nthr} BLAS threads" if threads else f"best of 8/32/{ncpu} BLAS threads (cores = the thread count of the best run)")
+                      + f", median {med:.3f} s/clip"}
 
 
-def ag_split_sample(device, n_clips):
-    """BASELINE configs[2] stand-in on a sample of the split: synthetic clips with the Action Genome test split's
-    frames-per-clip (tests/golden/ag_test_clip_lengths.json: the first `n_clips` of its 1 737 clips), 1..6 pairs per frame,
-    packed 64 per forward, each pack scored by ONE device-evaluator call (tools/ag_split_bench.py runs all of them)."""
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this process has
+    made no GPU call and makes none), each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, let
+    rank 0 print the one JSON line on the inherited stdout, and return the first non-zero exit code (the remaining
+    children are then terminated by their own PIDs) or 0."""
+    ndev = torch.cuda.device_count()                     # counts devices without initialising the runtime
+    if ndev < n and "BENCH_FORCE_DEVICE" not in os.environ:
+        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0:
+                rc = code
+    for pr in live:                                      # a rank failed: stop the others (exact PIDs we started)
+        pr.terminate()
+    for pr in live:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    return rc
+
+
+def pci_bus_id(ordinal):
+    """PCI bus id of a HIP device ordinal ("0000:c5:00.0")."""
+    pr = torch.cuda.get_device_properties(ordinal)
+    if all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    try:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
+            return buf.value.decode().lower()
+    except Exception:
+        pass
+    return None
+
+
+def strong_scaling(env, model, name, clip_specs, pack, cost_of):
+    """STRONG scaling: a FIXED set of clips (the same whatever N is), sharded over the ranks with `assign_clips`
+    (longest-processing-time first on `cost_of`), each rank forwards its own clips `pack` per pass, every round's
+    predictions are all-gathered (`PredictionGatherer`, one gather per round, asynchronous) and rank 0 scores ALL clips of
+    the round with the device evaluator in one call.  Timed: barrier -> last evaluator result on rank 0, max over ranks,
+    second pass of the process (the first warms the allocator).  Reported next to it: every rank's own busy time (its
+    forwards only) and the imbalance of the assignment -- the two things that can cost strong scaling here.
+
+    clip_specs[i] = (frames, pairs-per-frame counts or None for the Action Genome range 1..6).  Every rank builds the
+    METADATA of every clip (boxes, labels, pair_idx, ground truth: a deterministic function of the clip id) but the
+    FEATURES of its own clips only."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ag_split_bench as ag
+    from nl_vsgg_amd.lib.distributed import assign_clips
     from nl_vsgg_amd.lib.evaluation_recall_hip import PackedGroundTruth, SceneGraphEvaluator_HIP
-    with open(os.path.join(ROOT, "tests", "golden", "ag_test_clip_lengths.json")) as f:
-        lengths = json.load(f)["frames_per_clip"][:n_clips]
-    model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=ag.OBJ,
-                   enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(device)
-    model.eval(); model.check_indices = False
-    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()}, strict=False)
-    ev = SceneGraphEvaluator_HIP(mode="predcls", AG_object_classes=ag.OBJ, AG_all_predicates=ag.ATT + ag.SPA + ag.CON,
-                                 AG_attention_predicates=ag.ATT, AG_spatial_predicates=ag.SPA, AG_contacting_predicates=ag.CON,
-                                 iou_threshold=0.5)
-    ev.register_container()
-    rng = np.random.default_rng(2024)
-    gen = torch.Generator(device=device).manual_seed(2024)
-    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
-    chunk = [ag.make_clip(rng, gen, lengths[i], device) for i in order]
-    # ground truth of each pack of 64 clips as one device table (data preparation, untimed like the clips themselves)
-    group_gt = {i: PackedGroundTruth.concat([gt for _, gt in chunk[i:i + 64]]) for i in range(0, len(chunk), 64)}
-    for g in group_gt.values():
-        g.on(device)
+    world, rank, device = env.world, env.rank, env.device
+    n = len(clip_specs)
+    costs = [cost_of(sp) for sp in clip_specs]
+    owner = assign_clips(costs, world)
+    order = sorted(range(n), key=lambda i: (-costs[i], i))                     # heaviest first inside every rank
+    lists = [[i for i in order if owner[i] == r] for r in range(world)]
+    packs = [[l[j:j + pack] for j in range(0, len(l), pack)] for l in lists]
+    rounds = max(len(pk) for pk in packs)
+
+    def build(i, features):
+        T, counts = clip_specs[i]
+        rng = np.random.default_rng([2024, i])
+        gen = torch.Generator(device=device).manual_seed(2024 + i)
+        return ag.make_clip(rng, gen, T, device, counts=counts, features=features)
+
+    mine = {i: build(i, True) for i in lists[rank]}
     ekw = dict(mode="predcls", AG_object_classes=ag.OBJ, AG_all_predicates=ag.ATT + ag.SPA + ag.CON,
                AG_attention_predicates=ag.ATT, AG_spatial_predicates=ag.SPA, AG_contacting_predicates=ag.CON, iou_threshold=0.5)
+    # rank 0, per round: the packed metadata + ground truth of the round's clips of ALL ranks in (rank, position) order --
+    # data preparation, like the clips themselves
+    round_meta, round_gt, round_rows = [], [], []
+    if rank == 0:
+        for r_ in range(rounds):
+            ents, gts, rows = [], [], []
+            for q in range(world):
+                ids = packs[q][r_] if r_ < len(packs[q]) else []
+                cl = [mine[i] if i in mine else build(i, False) for i in ids]
+                ents += [{k: c[0][k] for k in ("boxes", "labels", "scores", "pair_idx", "im_idx", "frame_counts", "num_frames")}
+                         for c in cl]
+                gts += [c[1] for c in cl]
+                rows.append(sum(int(c[0]["pair_idx"].shape[0]) for c in cl))
+            meta = pack_clips(ents)
+            g = PackedGroundTruth.concat(gts)
+            g.on(device)
+            round_meta.append({k: meta[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores", "num_frames")})
+            round_gt.append(g); round_rows.append(rows)
+    my_rows = [sum(int(mine[i][0]["pair_idx"].shape[0]) for i in pk) for pk in packs[rank]]
+    rows_cap = max(max((sum(int(np.sum(clip_specs[i][1])) if clip_specs[i][1] is not None else 6 * clip_specs[i][0]
+                            for i in pk) for pk in pq), default=1) for pq in packs)
+    gatherer = PredictionGatherer(rows_cap, pack, cols=26, device=device, depth=2) if world > 1 else None
+    model.reserve(max(my_rows, default=1), max((sum(int(mine[i][0]["labels"].shape[0]) for i in pk) for pk in packs[rank]),
+                                               default=1))
+    busy = [0.0]
 
-    def loop(e):
-        for i in range(0, len(chunk), 64):
-            e.evaluate_packed(group_gt[i], model(pack_clips([dict(c[0]) for c in chunk[i:i + 64]])))   # one call per pack
-        e.calculate_mean_recall()
+    def one_pass(ev):
+        tickets = []
+        t_start = time.perf_counter()
+        for r_ in range(rounds):
+            ids = packs[rank][r_] if r_ < len(packs[rank]) else []
+            rows = None
+            if ids:
+                pred = model(pack_clips([dict(mine[i][0]) for i in ids]))
+                rows = pack_predictions(pred, out=gatherer.payload() if gatherer else None)
+            if gatherer is not None:
+                if rows is None:
+                    rows = gatherer.payload()[:0]
+                tickets.append(gatherer.submit(rows, ids, [int(mine[i][0]["pair_idx"].shape[0]) for i in ids]))
+                # score the PREVIOUS round while this one's gather is in flight (its buffers are valid for one more submit)
+                if rank == 0 and r_ >= 1:
+                    score(ev, r_ - 1, gatherer.gathered(tickets[r_ - 1])[0])
+            elif rank == 0:
+                score(ev, r_, rows[None])
+        done = torch.cuda.Event(); done.record()
+        if gatherer is not None and rank == 0 and rounds:
+            score(ev, rounds - 1, gatherer.gathered(tickets[-1])[0])
+        done.synchronize()
+        busy[0] = time.perf_counter() - t_start            # this rank's own forwards (enqueue + device), evaluator excluded on ranks > 0
+        if rank == 0:
+            ev.calculate_mean_recall()                     # flushes the device evaluator: every hit table tallied
         torch.cuda.synchronize()
-    # one untimed pass first (a throw-away evaluator): the packs' buffers come from the caching allocator afterwards and
-    # the evaluator's kernel / pinned pool exist -- the timed pass is the steady state of a long split, not its first second
-    w = SceneGraphEvaluator_HIP(**ekw); w.register_container()
-    loop(w)
-    del w
+
+    def score(ev, r_, gathered):
+        parts = [gathered[q, :nrows] for q, nrows in enumerate(round_rows[r_]) if nrows]
+        rows = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        p = dict(round_meta[r_])
+        p["attention_distribution"] = rows[:, :3].contiguous()
+        p["spatial_distribution"] = rows[:, 3:9].contiguous()
+        p["contacting_distribution"] = rows[:, 9:26].contiguous()
+        ev.evaluate_packed(round_gt[r_], p)
+
+    def fresh():
+        if rank != 0:
+            return None
+        e = SceneGraphEvaluator_HIP(**ekw); e.register_container()
+        return e
+    one_pass(fresh())                                      # untimed: allocator, evaluator kernels, pinned pool
+    env.barrier(gatherer)
+    ev = fresh()
     t0 = time.perf_counter()
-    loop(ev)
-    dt = time.perf_counter() - t0
-    frames = sum(c[0]["num_frames"] for c in chunk)
-    return {"value": frames / dt, "seconds": dt, "clips": len(chunk), "frames": frames,
-            "pairs": sum(int(c[0]["pair_idx"].shape[0]) for c in chunk),
-            "config": {"workload": "Action-Genome-test-split-shaped synthetic clips (frames per clip from ag_test_id.pkl, 1..6 pairs "
-                                   "per frame), STTran PredCls + device Recall@K evaluator, 64 clips per forward, features "
-                                   "resident in HBM; the real split's annotations / features are not shipped with the reference"},
-            "recall_with_constraint": {str(k): round(float(v), 4) for k, v in ev.summary()["recall"].items()}}
+    one_pass(ev)
+    env.barrier(gatherer)
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    model.sync_check()
+    frames = sum(sp[0] for sp in clip_specs)
+    loads = [sum(costs[i] for i in l) for l in lists]
+    per_rank = [{"rank": rank, "clips": len(lists[rank]), "frames": sum(clip_specs[i][0] for i in lists[rank]),
+                 "passes": len(packs[rank]), "busy_s": busy[0]}]
+    if world > 1:
+        allr = [None] * world
+        env.dist.all_gather_object(allr, per_rank[0])
+        per_rank = allr
+    res = {"value": frames / dt, "unit": "frames/s", "seconds": dt, "clips": n, "frames": frames, "ranks": world,
+           "clips_per_forward": pack, "rounds": rounds, "per_rank": per_rank,
+           "lpt_imbalance": max(loads) / (sum(loads) / world) if sum(loads) else 1.0,
+           "busy_imbalance": max(p_["busy_s"] for p_ in per_rank) / (sum(p_["busy_s"] for p_ in per_rank) / world),
+           "config": {"workload": name, "sharding": f"assign_clips (LPT on pairs x frames) over {world} rank(s), one all-gather of "
+                                                    f"[pairs, 26] rows per round, rank 0 scores every clip with the device evaluator"}}
+    if rank == 0:
+        res["recall_with_constraint"] = {str(k): round(float(v), 4) for k, v in ev.summary()["recall"].items()}
+    del mine, round_meta, round_gt
+    torch.cuda.empty_cache()
+    return res
 
 
 class Env:
@@ -179,6 +331,25 @@ class Env:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND", "nccl"))    # nccl == RCCL on ROCm
             self.dist = dist
+
+    def devices(self):
+        """what every rank ran on, all-gathered: lets the reader check that the N ranks sat on N distinct GPUs"""
+        pr = torch.cuda.get_device_properties(self.local)
+        mine = {"rank": self.rank, "device": self.local, "pci_bus_id": pci_bus_id(self.local), "name": pr.name,
+                "uuid": str(getattr(pr, "uuid", "")) or None, "pid": os.getpid(),
+                "backend": self.dist.get_backend() if self.dist else None}
+        if self.world == 1:
+            return [mine]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, mine)
+        return out
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
     def barrier(self, gatherer=None):
         if self.world > 1:
@@ -239,7 +410,7 @@ def by_kernel_tables(entries, forwards):
 
 
 def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=False, roofline=True, one_clip=False,
-                 pcie=False):
+                 pcie=False, repeats=1, alone=False):
     """Warm-up, EXACTLY `steps` timed steps between barrier + synchronize (max over ranks), then the optional legs."""
     world, device, dist = env.world, env.device, env.dist
     T, N, _ = SHAPES[workload]
@@ -276,21 +447,24 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
             g.replay()
             return gpred
         run(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pred = run()
-    env.barrier(gatherer)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # EXACTLY `steps` timed steps between barrier + synchronize, max over ranks -- `repeats` times back to back; the
+    # line's value is the MEDIAN repeat (a 20-step region is 0.6 s: one repeat alone moves +-1 % with the box's clocks)
+    times = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pred = run()
+        env.barrier(gatherer)
+        times.append(env.max_over_ranks(time.perf_counter() - t0))
+    elapsed = float(np.median(times))
     assert torch.isfinite(pred["attention_distribution"]).all()
+    model.sync_check()                  # device-side flags (clamped indices, skipped DSG-DETR sequences) raise here
 
     frames_per_step = world * cps * T
     res = {
         "value": frames_per_step * steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps,
-        "steps": steps, "warmup": warmup,
+        "steps": steps, "warmup": warmup, "repeats": [frames_per_step * steps / t for t in times],
+        "timed_seconds": sum(times),
         "config": {"workload": (f"synthetic {T} frames x {N} boxes x 2048-d region features, STTran PredCls forward "
                                 f"(enc 1 / dec 3 layers, d=1936), inputs resident in HBM") if model_kind == "sttran" else
                                (f"synthetic {T} frames x {N} boxes x 2048-d region features, DSG-DETR sgdet forward "
@@ -313,6 +487,24 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
         torch.cuda.synchronize()
         res["allgather_ms"] = 1e3 * (time.perf_counter() - t0) / 20
         res["allgather_bytes_per_rank"] = P * 26 * 4
+
+        if alone:
+            # the same per-GPU workload on rank 0 ALONE while the other ranks wait at the barrier: what one GPU of this
+            # node reaches without neighbours (no gather) -- the reference point of the weak-scaling `value`
+            dt = None
+            if env.rank == 0:
+                for _ in range(2):
+                    model(dict(batch))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model(dict(batch))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            env.barrier()
+            if env.rank == 0:
+                res["one_rank_alone"] = {"value": cps * T * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps,
+                                         "note": "rank 0 runs the same per-GPU steps while the other ranks idle; no gather"}
 
     # ---- the same clip shape, ONE clip per pass (the reference's own batch size; not `value`) -------------
     if one_clip and cps > 1 and world == 1:
@@ -440,6 +632,7 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric reads x2 + writes)",
             "traffic_source": traffic_src, "traffic_commit": traffic_commit,
+            "traffic_measured_in_run": False,      # PMC counters cannot be read in-process: a static, commit-stamped figure
             "algorithmic_bytes_per_launch": gm["bytes"] / max(gm["launches"], 1),
             "launches_per_step": gm["launches"] / fw,
             "avg_launch_us": 1e3 * gm["ms"] / max(gm["launches"], 1),
@@ -471,7 +664,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="16x12", choices=sorted(SHAPES))
+    ap.add_argument("--workload", default=None, choices=sorted(SHAPES),
+                    help="clip shape of the line's value; default 16x12 (BASELINE configs[1]) on one GPU, 64x36 (configs[3]) on N > 1")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps; the value is their median")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block")
+    ap.add_argument("--strong-clips", type=int, default=64, help="clips of 64x36 in the strong-scaling set")
+    ap.add_argument("--ag-clips", type=int, default=1737, help="clips of the Action-Genome-split-shaped strong-scaling set")
     ap.add_argument("--clips-per-step", type=int, default=0, help="0 = default for the workload")
     ap.add_argument("--model", default="sttran", choices=["sttran", "dsgdetr"],
                     help="dsgdetr = BASELINE.json configs[4]: lib/dsg_detr.py (sgdet branch) on the same kernels")
@@ -493,9 +691,18 @@ def main():
     args = ap.parse_args()
     if args.profile_only_batch:
         args.no_cpu_baseline = args.no_roofline = args.no_extra_workloads = True
+        args.repeats = 1
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves, as fresh children, before anything here touches a GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     env = Env(args)
     rank, world, device = env.rank, env.world, env.device
+    # N > 1: the line's value is measured on BASELINE configs[3]'s clip (64x36), the workload north_star quotes the
+    # scaling target on; N = 1: configs[1] (16x12).  `--workload` overrides.
+    if args.workload is None:
+        args.workload = "64x36" if world > 1 else "16x12"
+    other = "16x12" if args.workload == "64x36" else "64x36"
     T, N, cps_default = SHAPES[args.workload]
     cps = args.clips_per_step or cps_default
     if args.model == "dsgdetr":
@@ -516,7 +723,8 @@ def main():
 
     extras = not args.no_extra_workloads
     main_res = run_workload(env, model, args.model, args.workload, cps, args.steps, args.warmup, graph=args.graph,
-                            roofline=not args.no_roofline, one_clip=extras, pcie=args.pcie)
+                            roofline=not args.no_roofline, one_clip=extras, pcie=args.pcie, repeats=args.repeats,
+                            alone=extras)
     result = {
         "metric": "frames/sec (PredCls inference)" if args.model == "sttran" else "frames/sec (SGDet inference, DSG-DETR)",
         "value": main_res["value"], "unit": "frames/s",
@@ -527,10 +735,20 @@ def main():
                                                          "nn.Linear GEMMs; f32 elsewhere",
         "data": "synthetic",
         "config": main_res["config"],
+        "repeats": main_res["repeats"], "timed_seconds": main_res["timed_seconds"],
+        "value_note": f"median of {len(main_res['repeats'])} back-to-back timed regions of exactly {args.steps} steps each",
     }
+    devs = env.devices()
+    result["ranks_seen"] = env.dist.get_world_size() if env.dist else 1
+    result["devices"] = devs
+    result["distinct_devices"] = len({(d["pci_bus_id"], d["uuid"]) if (d["pci_bus_id"] or d["uuid"]) else ("ordinal", d["device"])
+                                      for d in devs})
     if world > 1:
         result["scaling_note"] = ("weak scaling: every rank runs the same per-GPU workload on its own clips, so value ~ N x "
-                                  "the 1-GPU value by construction unless the host glue or the per-step all-gather contends")
+                                  "the 1-GPU value by construction unless the host glue or the per-step all-gather contends; "
+                                  "compare with `one_rank_alone` of this line or workloads['64x36'] of the --gpus 1 line (the "
+                                  "--gpus 1 line's own `value` is the 16x12 clip, BASELINE configs[1]); `strong_scaling` holds "
+                                  "the fixed-work legs")
     if "batch_sweep" in main_res:                        # 1 clip / the round 1-2 default / this run's batch, one list
         sweep = []
         if "one_clip_per_pass" in main_res:
@@ -539,19 +757,42 @@ def main():
         sweep += main_res["batch_sweep"]
         sweep.append({"clips_per_step": cps, "value": main_res["value"], "ms_per_step": main_res["ms_per_step"]})
         result["batch_sweep"] = sweep
-    for k in ("allgather_ms", "allgather_bytes_per_rank", "one_clip_per_pass", "pcie_inclusive", "pcie_inclusive_overlapped",
-              "roofline", "reference_arithmetic"):
+    for k in ("allgather_ms", "allgather_bytes_per_rank", "one_rank_alone", "one_clip_per_pass", "pcie_inclusive",
+              "pcie_inclusive_overlapped", "roofline", "reference_arithmetic"):
         if k in main_res:
             result[k] = main_res[k]
-    # ---- the other BASELINE workload in the same run (north_star's scaling target is quoted on 64x36) ----
-    if extras and args.model == "sttran" and args.workload == "16x12":
+    # ---- the other BASELINE clip shape in the same run ----
+    if extras and args.model == "sttran":
         steps2 = max(5, min(args.steps, 20))
-        w = run_workload(env, model, args.model, "64x36", SHAPES["64x36"][2], steps2, min(args.warmup, 3),
-                         roofline=not args.no_roofline)
+        w = run_workload(env, model, args.model, other, SHAPES[other][2], steps2, min(args.warmup, 3),
+                         roofline=not args.no_roofline, one_clip=(world == 1 and other == "64x36"))
         w.pop("unit", None)
         if "roofline" in w:                              # keep the line readable: per-kernel rows, not per-shape
             w["roofline"].pop("by_shape", None)
-        result["workloads"] = {"64x36": w}
+        result["workloads"] = {other: w}
+    # ---- STRONG scaling (fixed work, any N): 64 clips of 64x36, and the Action-Genome-test-split-shaped set (configs[2]'s
+    #      stand-in: frames per clip of ag_test_id.pkl, 1..6 pairs per frame) -- model + gather + device evaluator ----
+    if extras and args.model == "sttran" and args.gemm_engine == "fp32" and not args.no_strong:
+        result["strong_scaling"] = {}
+        with open(os.path.join(ROOT, "tests", "golden", "ag_test_clip_lengths.json")) as f:
+            lengths = json.load(f)["frames_per_clip"][:args.ag_clips]
+        sets = [("64x36_x64", "64 clips of 64 frames x 36 boxes (BASELINE configs[3]'s clip), STTran PredCls + device Recall@K "
+                              "evaluator, 4 clips per forward", [(64, [35] * 64)] * args.strong_clips, 4,
+                 lambda sp: float(sp[0]) * float(np.sum(sp[1]))),
+                ("ag_split_shaped", f"Action-Genome-test-split-shaped synthetic clips ({len(lengths)} clips, frames per clip from "
+                                    "ag_test_id.pkl, 1..6 pairs per frame), STTran PredCls + device Recall@K evaluator, 64 clips "
+                                    "per forward, features resident in HBM; the real split's annotations / features are not "
+                                    "shipped with the reference", [(int(t), None) for t in lengths], 64,
+                 lambda sp: float(sp[0]) * 3.5 * float(sp[0]))]
+        for key, name, specs, pack, cost in sets:
+            try:
+                result["strong_scaling"][key] = strong_scaling(env, model, name, specs, pack, cost)
+            except Exception as e:                       # an extra block must never cost the line ...
+                if world > 1:
+                    raise                                # ... but ranks must not diverge: with N > 1 a failure is fatal
+                result["strong_scaling"][key] = {"error": repr(e)}
+        if world == 1 and "error" not in result["strong_scaling"]["ag_split_shaped"]:
+            result.setdefault("workloads", {})["ag_split_shaped"] = result["strong_scaling"]["ag_split_shaped"]
     # ---- EXPERIMENT block: the same workload with the bf16x3 GEMM engine, and how far its outputs are from the exact
     #      engine's on the same batch (never `value`)
     if extras and world == 1 and args.model == "sttran" and args.workload == "16x12" and args.gemm_engine == "fp32":
@@ -568,6 +809,7 @@ def main():
             w["note"] = ("EXPERIMENT, opt-in (model.gemm_engine = 'bf16x3'): nn.Linear GEMMs with M >= 512, the union 1x1 conv and "
                          "the conv3x3 on v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 planes, six cross products, fp32 "
                          "accumulate; error vs fp64 no larger than the exact fp32-MFMA engine's (tests/test_kernels_gpu.py)")
+            w.pop("reference_arithmetic", None)          # priced against the fp32 pipe: meaningless for this engine
             result["workloads"]["16x12_bf16x3"] = w
         except Exception as e:
             result["workloads"]["16x12_bf16x3"] = {"error": repr(e)}
@@ -588,19 +830,21 @@ def main():
             w.pop("unit", None)
             if "roofline" in w:
                 w["roofline"].pop("by_shape", None)
+            if rank == 0 and not args.no_cpu_baseline:
+                w["cpu_baseline"] = cpu_baseline(16, 12, dsd, model_kind="dsgdetr", budget_s=6.0)
             result["workloads"]["dsgdetr_16x12"] = w
             del dm, dsd
             torch.cuda.empty_cache()
         except Exception as e:                           # an extra block must never cost the line
             result["workloads"]["dsgdetr_16x12"] = {"error": repr(e)}
-        try:                                             # configs[2] stand-in: the loop of tools/test_STTran.py:75-92 on AG-shaped clips
-            result["workloads"]["ag_split_shaped"] = ag_split_sample(device, 256)
-        except Exception as e:
-            result["workloads"]["ag_split_shaped"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "sttran":
         result["cpu_baseline"] = cpu_baseline(T, N, sd)
+        if extras and "workloads" in result and other in result["workloads"] and "error" not in result["workloads"][other]:
+            # the other clip shape's CPU number, on the thread count that won above (one warm-up + one timed forward)
+            result["workloads"][other]["cpu_baseline"] = cpu_baseline(*SHAPES[other][:2], sd, budget_s=14.0,
+                                                                      threads=result["cpu_baseline"]["cores"])
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         env.barrier()
         env.dist.destroy_process_group()

@@ -181,12 +181,13 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
         const int row = tid % BM, kg = (tid / BM) * AV + i;
         const int n = m0 + row < M ? m0 + row : 0;
         const int p = n / kUHW, hw = n - p * kUHW;
-        pa[i] = A.ptr + (int64_t)p * A.ld + (int64_t)(ks0 * kBK + kg * 4) * kUHW + hw;
+        pa[i] = A.ptr + (A.rowoff ? A.rowoff[p] : (int64_t)p * A.ld) + (int64_t)(ks0 * kBK + kg * 4) * kUHW + hw;
         wa[i] = row * 64 + (((kg >> 1) ^ ((row >> 2) & 3)) * 16) + (kg & 1) * 8;
       } else {
         const int row = (tid >> 3) + i * (NT >> 3);
         const int g = m0 + row;
-        pa[i] = A.ptr + (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + ks0 * kBK + (tid & 7) * 4;
+        pa[i] = A.ptr + (A.rowoff ? (g < M ? A.rowoff[g] : (int64_t)0)
+                                  : (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + ks0 * kBK + (tid & 7) * 4;
         wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
       }
     }

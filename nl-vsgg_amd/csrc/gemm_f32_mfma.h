@@ -42,6 +42,11 @@ struct GemmOperand {
   int64_t ld;          // row stride in floats (multiple of 4, 16-byte aligned base)
   const int* rowidx;   // optional gather: logical row r reads physical row rowidx[r]
   int aux;             // B_UNION_FLAT: number of pairs P (ld = pair stride K*49)
+  // Optional gather by ELEMENT OFFSET: logical row r (B_UNION_FLAT: pair r) starts at ptr + rowoff[r] floats.  This is
+  // how a batch of clips is read where the caller left it (SttranInputs' per-clip pointer tables): the rows of one
+  // operand then live in several allocations, `ptr` is the first clip's tensor and an offset may be any signed
+  // distance inside the device's address space (pair_prep_kernel writes them).  Takes precedence over rowidx.
+  const int64_t* rowoff;
 };
 
 // B-operand kinds.  B_KMAJOR: rows of W[N][K], K-contiguous (nn.Linear weights, im2col rows).
@@ -328,7 +333,8 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + (tid >> 3) + i * (NT >> 3);
       va[i] = g < M;
-      pa[i] = A.ptr + (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld + kq4;
+      pa[i] = A.ptr + (A.rowoff ? (va[i] ? A.rowoff[g] : (int64_t)0)
+                                : (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + kq4;
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
@@ -339,7 +345,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         vb[i] = n < N;
         const int nn = vb[i] ? n : 0, p = nn / kUHW, hw = nn - p * kUHW;
         sb[i] = (BM + col) * kLdsStride + kg * 4;
-        pb[i] = B.ptr + (int64_t)p * B.ld + kg * 4 * kUHW + hw;
+        pb[i] = B.ptr + (B.rowoff ? B.rowoff[p] : (int64_t)p * B.ld) + kg * 4 * kUHW + hw;
       } else if constexpr (CONV) {
         const int g = n0 + (tid >> 3) + i * (NT >> 3);
         vb[i] = g < N;

@@ -14,11 +14,7 @@ struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
 // (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
-    {128, 256, 0.80f, 1},    // TILE_RESERVED (round 1's union-conv tile; never chosen by plan_gemm, no instantiation)
-    // gemm_dma.h tiles: LDS = 64 / 96 / 48 / 32 KB per workgroup
-    {128, 128, 0.92f, 2}, {256, 128, 0.92f, 1}, {128, 64, 0.88f, 3}, {64, 64, 0.80f, 4}};
-static bool is_dma_tile(int t) { return t >= TILE_D128x128 && t <= TILE_D64x64; }
+    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2}};
 
 // Hybrid data-parallel + stream-K schedule of one GEMM: G persistent workgroups each run dp_per_wg whole
 // tiles; the tiles_sk leftover tiles (< G) are cut into g_sk equal iteration ranges.

@@ -4,9 +4,6 @@
 #include <stdint.h>
 
 #include "gemm_f32_mfma.h"
-#ifdef STTRAN_GEMM_DMA
-#include "gemm_dma.h"
-#endif
 
 namespace sttran {
 
@@ -34,9 +31,8 @@ struct DeviceMarks {
 int num_cus();   // compute units of the current device (cached per ordinal)
 
 // ---- GEMM ------------------------------------------------------------------------------
-// 1..5: gemm_f32_mfma.h (register-staged); 6..9: gemm_dma.h (LDS-DMA staging, vector epilogue; padded operands only)
-enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_RESERVED = 5,
-       TILE_D128x128 = 6, TILE_D256x128 = 7, TILE_D128x64 = 8, TILE_D64x64 = 9, TILE_COUNT = 10 };
+// tiles of gemm_f32_mfma.h (ids are part of the sttran_debug_gemm test hook: keep them stable)
+enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_COUNT = 5 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);
@@ -61,21 +57,40 @@ hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* plane
 // union_func1 on the same engine: planes = [3][256][K] bf16 of union_func1.weight
 hipError_t launch_mask_conv2_x3(hipStream_t s, const void* planes, const float* c2, const float* bias, const float* scale,
                                 const float* shift, float* V, int P, float* slab);
-hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const void* planes, const float* bias, float* V, int P, int K,
-                                float* slab);
+hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const int64_t* u_off, const void* planes, const float* bias,
+                                float* V, int P, int K, float* slab);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
-// pair_idx/labels (int64) -> int32 gather indices + the two class-embedding column blocks of x
-hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int P, int B,
-                            int num_classes, const float* emb1, const float* emb2, int emb_dim,
-                            int* subj_idx, int* obj_idx, float* x, int ldx, int col_off, int* err_flag);
+// Where the inputs of one call live: n chunks, chunk c = the tensors of one clip as the caller passed them (SttranInputs'
+// per-clip pointer tables) or ONE chunk = the whole contiguous batch.  All members are DEVICE arrays: the two prefix
+// arrays have n + 1 entries, the pointer arrays n (boxes / dist: sgdet only).  pair_idx rows of a chunk are local to
+// the chunk's boxes.
+struct ChunkTable {
+  int n;
+  const int64_t* pair_start;
+  const int64_t* box_start;
+  const void* const* features;
+  const void* const* pair_idx;
+  const void* const* labels;
+  const void* const* union_feat;
+  const void* const* masks;
+  const void* const* boxes;
+  const void* const* dist;
+};
+// per pair: element offsets of its feature rows [2][P] / union_feat block [P] / spatial_masks block [P] from chunk 0's
+// tensors, the two class-embedding column blocks of x, and (optional, DSG-DETR) object class + global subject row
+hipError_t launch_pair_prep(hipStream_t s, const ChunkTable& tab, int P, int feat_dim, int num_classes, const float* emb1,
+                            const float* emb2, int emb_dim, int64_t* feat_off, int64_t* union_off, int64_t* mask_off,
+                            int* cls_of_pair, int* subj_of_pair, float* x, int ldx, int col_off, int* err_flag);
 // Conv2d(2,128,k7,s2,p3) -> ReLU -> BN -> MaxPool(3,2,1) of the spatial masks in one kernel (lib/sttran.py:337-341):
 // masks [P,2,27,27] -> c2 [P,128,7,7].  w0p = conv.0.weight re-ordered to [128][13][2][4] (tap group, input
 // channel, tap in group; taps 49..51 zero).
-hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w0p, const float* bias,
-                                  const float* scale, const float* shift, float* c2, int P);
+// mask_off (optional): pair p's [2,27,27] block starts at masks + mask_off[p] floats (else at masks + 1458 p)
+hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const int64_t* mask_off, const float* w0p,
+                                  const float* bias, const float* scale, const float* shift, float* c2, int P);
 // union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]   (V already holds the mask-conv branch)
-hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V,
+// u_off (optional): pair p's [K,7,7] block starts at U + u_off[p] floats (else at U + 49 K p)
+hipError_t launch_union_conv(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
                              int P, int K, float* slab);
 
 // DSG-DETR class sequences built on the device (lib/dsg_detr.py:545-555): clip_start [num_clips + 1] pair ranges;
@@ -121,10 +136,9 @@ hipError_t launch_gather_add_rows(hipStream_t s, const float* src, int64_t lds, 
 
 // ---- ObjectClassifier sgdet+wks (lib/sttran.py:173-184) ---------------------------------------
 // z[b] = [features[b] | distribution[b] @ E0 | ReLU(Linear(BN(center_size(box))))]   -> [B, 2376]
-hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,
-                              const float* E0, const float* pos_scale, const float* pos_shift,
-                              const float* pos_w, const float* pos_b, float* z, int64_t ldz, int B, int feat_dim,
-                              int ncls, int emb_dim);
+hipError_t launch_objcls_prep(hipStream_t s, const ChunkTable& tab, const float* E0, const float* pos_scale,
+                              const float* pos_shift, const float* pos_w, const float* pos_b, float* z, int64_t ldz, int B,
+                              int feat_dim, int ncls, int emb_dim);
 
 // ---- SGDet without weak supervision (lib/sttran.py:185-283): kernels_objcls.hip ------------------------
 size_t objcls_scratch_bytes(int64_t B, int T);

@@ -7,28 +7,57 @@
 namespace sttran {
 
 // ------------------------------------------------------------------------------------------
-// pair_prep: int64 pair_idx/labels -> int32 gather indices for the subj/obj FC GEMMs, and the two
-// class-embedding blocks of rel_features: x[p, off:off+200] = E1[labels[subj]],
-// x[p, off+200:off+400] = E2[labels[obj]]   (lib/sttran.py:390-396).
+// pair_prep: where every pair's inputs live, and the two class-embedding blocks of rel_features.
+//
+// The inputs of a call are a list of CHUNKS (ChunkTable, kernels.h): one chunk = one clip's tensors where the caller
+// left them (SttranInputs' per-clip pointer tables), or a single chunk holding the whole contiguous batch.  Per pair p
+// (chunk c, local pair lp, local box rows s / o from the chunk's own pair_idx):
+//   feat_off[0][p], feat_off[1][p] = element offset of the subject / object feature row from chunk 0's features
+//                                    (the A-operand row gather of the subj / obj FC GEMMs, GemmOperand::rowoff)
+//   union_off[p], mask_off[p]      = element offset of the pair's union_feat / spatial_masks block from chunk 0's
+//   x[p, off:off+200] = E1[labels[subj]],  x[p, off+200:off+400] = E2[labels[obj]]     (lib/sttran.py:390-396)
+//   cls_of_pair / subj_of_pair     = (DSG-DETR) class of the object box, GLOBAL row of the subject box
+// Out-of-range pair_idx / labels are clamped and flagged (err_flag bit 0), as before.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int chunk_of(const int64_t* __restrict__ start, int n, int64_t v) {
+  int lo = 0, hi = n;                       // last chunk c with start[c] <= v (empty chunks are skipped that way)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (start[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int64_t float_distance(const void* a, const void* b) {
+  return (reinterpret_cast<intptr_t>(a) - reinterpret_cast<intptr_t>(b)) / 4;
+}
+
 __global__ void __launch_bounds__(128)
-pair_prep_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restrict__ labels, int P, int B,
-                 int num_classes, const float* __restrict__ emb1, const float* __restrict__ emb2, int emb_dim,
-                 int* __restrict__ subj_idx, int* __restrict__ obj_idx, float* __restrict__ x, int ldx,
-                 int col_off, int* __restrict__ err_flag) {
+pair_prep_kernel(ChunkTable tab, int P, int feat_dim, int num_classes, const float* __restrict__ emb1,
+                 const float* __restrict__ emb2, int emb_dim, int64_t* __restrict__ feat_off, int64_t* __restrict__ union_off,
+                 int64_t* __restrict__ mask_off, int* __restrict__ cls_of_pair, int* __restrict__ subj_of_pair,
+                 float* __restrict__ x, int ldx, int col_off, int* __restrict__ err_flag) {
   const int p = blockIdx.x;
   if (p >= P) return;
-  int64_t s = pair_idx[2 * (int64_t)p], o = pair_idx[2 * (int64_t)p + 1];
+  const int c = chunk_of(tab.pair_start, tab.n, p);
+  const int64_t lp = p - tab.pair_start[c];
+  const int64_t B = tab.box_start[c + 1] - tab.box_start[c];
+  const int64_t* pair_idx = reinterpret_cast<const int64_t*>(tab.pair_idx[c]);
+  const int64_t* labels = reinterpret_cast<const int64_t*>(tab.labels[c]);
+  int64_t s = pair_idx[2 * lp], o = pair_idx[2 * lp + 1];
   bool bad = (s < 0 || s >= B || o < 0 || o >= B);
-  s = min(max(s, (int64_t)0), (int64_t)B - 1);
-  o = min(max(o, (int64_t)0), (int64_t)B - 1);
+  s = min(max(s, (int64_t)0), B - 1);
+  o = min(max(o, (int64_t)0), B - 1);
   int64_t ls = labels[s], lo = labels[o];
   bad = bad || ls < 0 || ls >= num_classes || lo < 0 || lo >= num_classes;
   ls = min(max(ls, (int64_t)0), (int64_t)num_classes - 1);
   lo = min(max(lo, (int64_t)0), (int64_t)num_classes - 1);
   if (threadIdx.x == 0) {
-    subj_idx[p] = (int)s;
-    obj_idx[p] = (int)o;
+    const int64_t f0 = float_distance(tab.features[c], tab.features[0]);
+    feat_off[p] = f0 + s * feat_dim;
+    feat_off[(int64_t)P + p] = f0 + o * feat_dim;
+    union_off[p] = float_distance(tab.union_feat[c], tab.union_feat[0]) + lp * ((int64_t)feat_dim * 49);
+    mask_off[p] = float_distance(tab.masks[c], tab.masks[0]) + lp * 1458;
+    if (cls_of_pair) { cls_of_pair[p] = (int)lo; subj_of_pair[p] = (int)(tab.box_start[c] + s); }
     if (bad) atomicOr(err_flag, 1);
   }
   const int half = threadIdx.x >> 6, t = threadIdx.x & 63;
@@ -39,11 +68,11 @@ pair_prep_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restrict
   }
 }
 
-hipError_t launch_pair_prep(hipStream_t s, const int64_t* pair_idx, const int64_t* labels, int P, int B,
-                            int num_classes, const float* emb1, const float* emb2, int emb_dim, int* subj_idx,
-                            int* obj_idx, float* x, int ldx, int col_off, int* err_flag) {
-  hipLaunchKernelGGL(pair_prep_kernel, dim3(P), dim3(128), 0, s, pair_idx, labels, P, B, num_classes, emb1,
-                     emb2, emb_dim, subj_idx, obj_idx, x, ldx, col_off, err_flag);
+hipError_t launch_pair_prep(hipStream_t s, const ChunkTable& tab, int P, int feat_dim, int num_classes, const float* emb1,
+                            const float* emb2, int emb_dim, int64_t* feat_off, int64_t* union_off, int64_t* mask_off,
+                            int* cls_of_pair, int* subj_of_pair, float* x, int ldx, int col_off, int* err_flag) {
+  hipLaunchKernelGGL(pair_prep_kernel, dim3(P), dim3(128), 0, s, tab, P, feat_dim, num_classes, emb1, emb2, emb_dim,
+                     feat_off, union_off, mask_off, cls_of_pair, subj_of_pair, x, ldx, col_off, err_flag);
   return hipGetLastError();
 }
 
@@ -105,24 +134,29 @@ hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int
 // center_size (lib/fpn/box_utils.py:51-63): wh = xy2 - xy1 + 1, c = xy1 + 0.5 wh.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-objcls_prep_kernel(const float* __restrict__ features, const float* __restrict__ dist,
-                   const float* __restrict__ boxes, const float* __restrict__ E0,
+objcls_prep_kernel(ChunkTable tab, const float* __restrict__ E0,
                    const float* __restrict__ pos_scale, const float* __restrict__ pos_shift,
                    const float* __restrict__ pos_w, const float* __restrict__ pos_b, float* __restrict__ z,
                    int64_t ldz, int B, int feat_dim, int ncls, int emb_dim) {
   __shared__ float d[64];
   __shared__ float cs[4];
   const int b = blockIdx.x, tid = threadIdx.x;
+  // box row b of the batch = row lb of chunk c (one chunk per clip when the caller passed pointer tables)
+  const int c = chunk_of(tab.box_start, tab.n, b);
+  const int64_t lb = b - tab.box_start[c];
+  const float* features = reinterpret_cast<const float*>(tab.features[c]) + lb * feat_dim;
+  const float* dist = reinterpret_cast<const float*>(tab.dist[c]) + lb * ncls;
+  const float* boxes = reinterpret_cast<const float*>(tab.boxes[c]) + lb * 5;
   float* zr = z + (int64_t)b * ldz;
-  if (tid < ncls) d[tid] = dist[(int64_t)b * ncls + tid];
+  if (tid < ncls) d[tid] = dist[tid];
   if (tid == 0) {
-    const float* bx = boxes + (int64_t)b * 5 + 1;
+    const float* bx = boxes + 1;
     const float w = bx[2] - bx[0] + 1.0f, h = bx[3] - bx[1] + 1.0f;
     const float c[4] = {bx[0] + 0.5f * w, bx[1] + 0.5f * h, w, h};
     for (int i = 0; i < 4; ++i) cs[i] = c[i] * pos_scale[i] + pos_shift[i];
   }
   for (int i = tid * 4; i < feat_dim; i += 1024)
-    *reinterpret_cast<f32x4*>(zr + i) = *reinterpret_cast<const f32x4*>(features + (int64_t)b * feat_dim + i);
+    *reinterpret_cast<f32x4*>(zr + i) = *reinterpret_cast<const f32x4*>(features + i);
   __syncthreads();
   for (int j = tid; j < emb_dim; j += 256) {
     float a = 0.f;
@@ -136,11 +170,11 @@ objcls_prep_kernel(const float* __restrict__ features, const float* __restrict__
   }
 }
 
-hipError_t launch_objcls_prep(hipStream_t s, const float* features, const float* dist, const float* boxes,
-                              const float* E0, const float* pos_scale, const float* pos_shift, const float* pos_w,
-                              const float* pos_b, float* z, int64_t ldz, int B, int feat_dim, int ncls, int emb_dim) {
+hipError_t launch_objcls_prep(hipStream_t s, const ChunkTable& tab, const float* E0, const float* pos_scale,
+                              const float* pos_shift, const float* pos_w, const float* pos_b, float* z, int64_t ldz, int B,
+                              int feat_dim, int ncls, int emb_dim) {
   if (ncls > 64 || ldz < feat_dim + emb_dim + 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(objcls_prep_kernel, dim3(B), dim3(256), 0, s, features, dist, boxes, E0, pos_scale,
+  hipLaunchKernelGGL(objcls_prep_kernel, dim3(B), dim3(256), 0, s, tab, E0, pos_scale,
                      pos_shift, pos_w, pos_b, z, ldz, B, feat_dim, ncls, emb_dim);
   return hipGetLastError();
 }
@@ -161,6 +195,8 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
                   int NC, int P, int pe_rows, int max_len, int* __restrict__ dec_off, int* __restrict__ dec_len, int* __restrict__ dec_src,
                   int* __restrict__ need, int* __restrict__ out_src, int* cls_of_pair, int* subj_of_pair, int* subj_of_tok,
                   int* first_of_tok, int* err_flag, int lds_ints) {
+  // pair_idx == nullptr: cls_of_pair / subj_of_pair were filled (and range-checked) by pair_prep_kernel already -- the
+  // forward's path, where the pairs of a batch may live in per-clip tensors; otherwise they are derived here
   // with room in LDS (2 ints per pair of the largest clip) the subject / first-occurrence tables of the clip live there
   // (rows s .. s+n of the global scratch otherwise): the two passes below read them O(sequence length) times per token
   extern __shared__ int dyn[];
@@ -174,6 +210,7 @@ dsg_layout_kernel(const int64_t* __restrict__ pair_idx, const int64_t* __restric
   if (tid < 64) hist[tid] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += 256) {
+    if (!pair_idx) { atomicAdd(&hist[cls_of_pair[s + i]], 1); continue; }
     int64_t sj = pair_idx[2 * (int64_t)(s + i)], ob = pair_idx[2 * (int64_t)(s + i) + 1];
     bool bad = sj < 0 || sj >= B || ob < 0 || ob >= B;
     sj = sj < 0 ? 0 : (sj >= B ? B - 1 : sj);

@@ -28,17 +28,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   double best_t = 1e300;
   const int64_t ksteps = (K + kBK - 1) / kBK;
   static const int env_tile = getenv("STTRAN_GEMM_TILE") ? atoi(getenv("STTRAN_GEMM_TILE")) : 0;   // experiments only
-  static const int env_gen = getenv("STTRAN_GEMM_GEN") ? atoi(getenv("STTRAN_GEMM_GEN")) : 0;      // 1 = old tiles only, 2 = DMA tiles only
-  if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT && env_tile != TILE_RESERVED) force_tile = env_tile;
+  if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT) force_tile = env_tile;
+  if (force_tile < 0 || force_tile >= TILE_COUNT) force_tile = 0;
   for (int t = 1; t < TILE_COUNT; ++t) {
-    if (t == TILE_RESERVED) continue;
     if (force_tile && t != force_tile) continue;
-    if (!force_tile && env_gen == 1 && is_dma_tile(t)) continue;
-    if (!force_tile && env_gen == 2 && !is_dma_tile(t)) continue;
-    if (!force_tile && env_gen != 2 && is_dma_tile(t)) continue;      // gemm_dma.h measured slower: opt-in only
-#ifndef STTRAN_GEMM_DMA
-    if (is_dma_tile(t)) continue;
-#endif
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -74,53 +67,6 @@ size_t gemm_slab_floats_max() {
 }
 size_t gemm_slab_bytes() { return gemm_slab_floats_max() * 4; }
 
-// ---- gemm_dma.h launch (experiment: built only with EXTRA=-DSTTRAN_GEMM_DMA) ------------------------------------
-#ifdef STTRAN_GEMM_DMA
-template <class T, class Epi>
-static hipError_t launch_dma_tile(hipStream_t s, int tile_id, const GemmOperand& A, const GemmOperand& B, int M, int N,
-                                  int K, float* slab, const Epi& epi) {
-  static DeviceMarks marks;
-  auto kern = gemm_dma_kernel<T, Epi>;
-  {
-    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
-    if (e != hipSuccess) return e;
-  }
-  const int tm = (M + T::BM - 1) / T::BM, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
-  const int ksteps = (K + kBK - 1) / kBK;
-  const SkPlan sp = sk_plan(tile_id, tiles, ksteps);
-  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
-  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
-  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
-  bool split = false;
-  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
-  if (split && !slab) return hipErrorInvalidValue;
-  // workgroups dispatched after the first one-per-CU wave walk their work in the opposite order (gemm_dma.h)
-  const int half = sp.G > num_cus() ? std::max(num_cus(), sp.G / 2) : sp.G;
-  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
-                     sp.g_sk, base, rem, half, slab, epi);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !split) return e;
-  hipLaunchKernelGGL((gemm_fixup_vec_kernel<T, Epi>), dim3(sp.tiles_sk, T::TM * T::TN * 4), dim3(T::NT), 0, s, M, N, tm, tn,
-                     ksteps, sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
-  return hipGetLastError();
-}
-
-template <class Epi>
-static hipError_t gemm_dma_generic(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
-                                   const Epi& epi, GemmPlan plan, float* slab) {
-  // LDS-DMA fetches 16-byte chunks: operand rows must be 16-byte aligned
-  if ((reinterpret_cast<uintptr_t>(A.ptr) & 15) || (reinterpret_cast<uintptr_t>(B.ptr) & 15) || (A.ld & 3) || (B.ld & 3))
-    return hipErrorInvalidValue;
-  switch (plan.tile) {
-    case TILE_D128x128: return launch_dma_tile<DmaTile<128, 128, 2, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_D256x128: return launch_dma_tile<DmaTile<256, 128, 4, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    case TILE_D128x64: return launch_dma_tile<DmaTile<128, 64, 2, 2>, Epi>(s, plan.tile, A, B, M, N, K, slab, epi);
-    default: return launch_dma_tile<DmaTile<64, 64, 2, 2>, Epi>(s, TILE_D64x64, A, B, M, N, K, slab, epi);
-  }
-}
-
-#endif  // STTRAN_GEMM_DMA
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // can EpiLinear run as 16-byte vectors?  (every pointer it dereferences at a column that is a multiple of 4)
 static bool epi_vectorizable(const EpiLinear& e, int N) {
@@ -134,15 +80,6 @@ static bool epi_vectorizable(const EpiLinear& e, int N) {
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                        const EpiLinear& epi, GemmPlan plan, float* slab, int padded) {
   if (M <= 0 || N <= 0) return hipSuccess;
-  if (is_dma_tile(plan.tile)) {
-#ifdef STTRAN_GEMM_DMA
-    if (!padded) return hipErrorInvalidValue;
-    if (epi_vectorizable(epi, N)) return gemm_dma_generic<EpiLinearV>(s, A, B, M, N, K, EpiLinearV{epi}, plan, slab);
-    return gemm_dma_generic<EpiScalar4<EpiLinear>>(s, A, B, M, N, K, EpiScalar4<EpiLinear>{epi}, plan, slab);
-#else
-    return hipErrorInvalidValue;
-#endif
-  }
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
   if (!padded) return gemm_linear_sel(s, A, B, M, N, K, epi, plan, slab);
@@ -152,17 +89,16 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
-  if (is_dma_tile(plan.tile)) return hipErrorInvalidValue;
   // N = 26: only the 64x64 tile makes sense (sttran_api.hip forces it); padded operands
   return launch_tile<GemmTile<64, 64, 2, 2, B_KMAJOR_PAD>, EpiScalar4<EpiHeads>>(s, TILE_64x64, A, B, M, N, K, slab, EpiScalar4<EpiHeads>{epi});
 }
 // union_func1: M = 256 out channels (A = W[256][K], one M-tile), N = 49 P columns (pair, hw) read in place from the
 // NCHW tensor (B_UNION_FLAT), hybrid data-parallel + stream-K schedule like every other GEMM
-hipError_t launch_union_conv(hipStream_t s, const float* U, const float* W, const float* bias, float* V, int P,
-                             int K, float* slab) {
+hipError_t launch_union_conv(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
+                             int P, int K, float* slab) {
   if (K % kBK != 0 || P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
   GemmOperand A{W, (int64_t)K, nullptr, 0};
-  GemmOperand B{U, (int64_t)K * kUHW, nullptr, P};
+  GemmOperand B{U, (int64_t)K * kUHW, nullptr, P, u_off};
   EpiUnionFlat epi{V, bias, 256, P};
   return launch_tile<TUnionFlat, EpiUnionFlat>(s, TILE_256x128, A, B, 256, P * kUHW, K, slab, epi);
 }

@@ -32,8 +32,9 @@ constexpr int kMcLdsFloats = 2 * kMcMask + 4 * kMcPoolCh * 196 + 3 * 128;
 __host__ __device__ constexpr int tap_offset(int t) { return t < 49 ? (t / 7) * kMcW + (t % 7) : 0; }
 
 __global__ void __launch_bounds__(256, 2)
-mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict__ w0p, const float* __restrict__ bias,
-                       const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ c2, int P) {
+mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restrict__ mask_off, const float* __restrict__ w0p,
+                       const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+                       float* __restrict__ c2, int P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
   float* mbuf = lds;                                                   // [2][kMcMask], double-buffered
@@ -73,12 +74,15 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
     const int ci = i / 729, r = i - ci * 729, y = r / 27, x = r - y * 27;
     return ci * kMcPlane + (y + 3) * kMcW + (x + 3);
   };
+  // pair p's masks: a batch of clips may leave them in per-clip tensors (mask_off, written by pair_prep_kernel)
+  auto mask_base = [&](int q) { return masks + (mask_off ? mask_off[q] : (int64_t)q * 1458); };
   int p = blockIdx.x;
   if (p < P) {
+    const float* mp = mask_base(p);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int i = tid + 256 * q;
-      if (i < 1458) mbuf[mask_slot(i)] = masks[(int64_t)p * 1458 + i];
+      if (i < 1458) mbuf[mask_slot(i)] = mp[i];
     }
   }
   __syncthreads();
@@ -88,10 +92,11 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
     float* nxt = mbuf + ((it + 1) & 1) * kMcMask;
     const int pn = p + gridDim.x;
     float pre[6];
+    const float* mpn = mask_base(pn < P ? pn : p);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int i = tid + 256 * q;
-      pre[q] = (pn < P && i < 1458) ? masks[(int64_t)pn * 1458 + i] : 0.f;
+      pre[q] = (pn < P && i < 1458) ? mpn[i] : 0.f;
     }
 
     f32x16 acc[7];
@@ -160,15 +165,15 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const float* __restrict_
 }  // namespace
 
 // w0p: conv.0.weight [128][2][7][7] re-ordered to [128][13 groups][2 channels][4 taps], taps 49..51 zero
-hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const float* w0p, const float* bias,
-                                  const float* scale, const float* shift, float* c2, int P) {
+hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const int64_t* mask_off, const float* w0p,
+                                  const float* bias, const float* scale, const float* shift, float* c2, int P) {
   if (P <= 0) return hipSuccess;
   static DeviceMarks marks;
   constexpr int lds_bytes = kMcLdsFloats * 4;
   hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(mask_conv1_pool_kernel), lds_bytes);
   if (e != hipSuccess) return e;
   const int grid = std::min(P, 2 * std::max(num_cus(), 1));
-  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, w0p, bias, scale, shift, c2, P);
+  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, mask_off, w0p, bias, scale, shift, c2, P);
   return hipGetLastError();
 }
 

@@ -69,16 +69,21 @@ class PredictionGatherer:
         self._meta_cache = {}
         self._n = 0
 
+    OVERFLOW = -2          # clip id of a record that says "this rank's submit did not fit its capacities"
+
     def _meta(self, clip_ids, clip_pairs):
         key = (tuple(int(i) for i in clip_ids), tuple(int(p) for p in clip_pairs))
         m = self._meta_cache.get(key)
         if m is None:
-            if len(key[0]) != len(key[1]) or len(key[0]) > self.clips_cap:
-                raise ValueError(f"{len(key[0])} clips / {len(key[1])} row counts exceed clips_cap={self.clips_cap}")
-            if sum(key[1]) > self.rows_cap:
-                raise ValueError(f"{sum(key[1])} prediction rows exceed rows_cap={self.rows_cap}")
+            if len(key[0]) != len(key[1]):
+                raise ValueError(f"{len(key[0])} clips but {len(key[1])} row counts")
             host = torch.full((self.clips_cap, 2), -1, dtype=torch.int64)
-            if key[0]:
+            if len(key[0]) > self.clips_cap or sum(key[1]) > self.rows_cap:
+                # The capacities are a rank-local fact: raising here would leave the OTHER ranks hanging in the
+                # all-gather.  The rank still takes part, sending an OVERFLOW record (and no rows); every rank's
+                # `result()` then raises the same error.
+                host[0, 0], host[0, 1] = self.OVERFLOW, sum(key[1])
+            elif key[0]:
                 host[: len(key[0]), 0] = torch.tensor(key[0], dtype=torch.int64)
                 host[: len(key[0]), 1] = torch.tensor(key[1], dtype=torch.int64)
             m = host.to(self.device)
@@ -109,7 +114,7 @@ class PredictionGatherer:
         if n != sum(int(p) for p in clip_pairs):
             raise ValueError("local_rows does not have sum(clip_pairs) rows")
         buf = self._payload[k]
-        if n and local_rows.data_ptr() != buf.data_ptr():
+        if n and n <= self.rows_cap and local_rows.data_ptr() != buf.data_ptr():
             buf[:n].copy_(local_rows)
         w1 = dist.all_gather_into_tensor(self._meta_all[k], meta, group=self.group, async_op=True)
         w2 = dist.all_gather_into_tensor(self._gathered[k], buf, group=self.group, async_op=True)
@@ -123,6 +128,18 @@ class PredictionGatherer:
         for k in range(self.depth):
             self._wait(k)
 
+    def gathered(self, ticket):
+        """The raw buffers of gather `ticket` WITHOUT a host synchronisation: ([world, rows_cap, cols] rows,
+        [world, clips_cap, 2] clip records), ordered after the gather on the current stream (gloo: the host waits).
+        For consumers that know every rank's layout already (bench.py's strong-scaling loop: the clip assignment is a
+        deterministic function every rank computes) and only need the rows.  Valid until the buffer set is reused."""
+        if not (self._n - self.depth <= ticket < self._n):
+            raise ValueError("that gather's buffers have been reused")
+        k = ticket % self.depth
+        self._wait(k)
+        return (self._gathered[k].view(self.world, self.rows_cap, self.cols),
+                self._meta_all[k].view(self.world, self.clips_cap, 2))
+
     def result(self, ticket):
         """{clip_id: [pairs, cols] tensor} of the gather `ticket` (views into its buffer set: valid until that set
         is reused, i.e. for the next `depth - 1` submits).  Synchronises: reads the clip records back."""
@@ -135,6 +152,9 @@ class PredictionGatherer:
         for r in range(self.world):
             off = r * self.rows_cap
             for cid, rows in meta[r].tolist():
+                if cid == self.OVERFLOW:
+                    raise ValueError(f"rank {r} submitted {rows} prediction rows / more clips than the gatherer's "
+                                     f"capacities (rows_cap={self.rows_cap}, clips_cap={self.clips_cap}) hold")
                 if cid < 0:
                     continue
                 out[int(cid)] = self._gathered[k][off: off + rows]

@@ -352,7 +352,7 @@ def pack_clips(entries):
         im.append(e["im_idx"] + frame_off)
         counts.append(fc)
         clips.append(len(fc))
-        box_off += int(e["features"].shape[0])
+        box_off += int(e["labels"].shape[0])
         frame_off += len(fc)
     for k in ("features", "labels", "union_feat", "spatial_masks", "boxes", "scores", "distribution"):
         if all(k in e for e in entries):
@@ -363,7 +363,7 @@ def pack_clips(entries):
     cat["clip_num_frames"] = np.asarray(clips, dtype=np.int32)
     cat["num_frames"] = int(frame_off)
     cat["_pairs_per_clip"] = [int(e["pair_idx"].shape[0]) for e in entries]
-    cat["_boxes_per_clip"] = [int(e["features"].shape[0]) for e in entries]
+    cat["_boxes_per_clip"] = [int(e["labels"].shape[0]) for e in entries]
     return cat
 
 

@@ -37,6 +37,7 @@ def test_bench_accepts_the_driver_flags():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup"):
         assert re.search(rf'add_argument\("{flag}"', src), flag
-    assert 'dist.all_reduce(t, op=dist.ReduceOp.MAX)' in src          # max over ranks
+    assert 'all_reduce(t, op=self.dist.ReduceOp.MAX)' in src           # max over ranks
+    assert "launch_ranks(args.gpus" in src and "os.exec" not in src     # --gpus N without a launcher: fresh children, never exec
     assert src.count("env.barrier(gatherer)") >= 2                      # both sides of the timed region
     assert "PredictionGatherer" in src                                  # the tested gather is the timed gather

@@ -1,6 +1,8 @@
-"""bench.py's N > 1 path (whole-clip sharding + the per-step all-gather of PredictionGatherer + max-over-ranks timing)
-run for real: two ranks as fresh child processes of `torch.distributed.run`, both on GPU 0, gloo instead of RCCL
-(BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist for exactly this).  The 8-GPU RCCL run is the driver's."""
+"""bench.py's N > 1 path (whole-clip sharding + the per-step all-gather of PredictionGatherer + max-over-ranks timing +
+the strong-scaling block) run for real: two ranks on GPU 0, gloo instead of RCCL (BENCH_FORCE_DEVICE /
+BENCH_DIST_BACKEND exist for exactly this) -- once started by plain `python bench.py --gpus 2` (bench.py launches its
+own ranks as fresh children, the form the driver uses), once as children of `torch.distributed.run`.  The 8-GPU RCCL
+run is the driver's."""
 import json
 import os
 import socket
@@ -29,21 +31,72 @@ def _run(cmd, extra_env=None, timeout=900):
     return json.loads(lines[0])
 
 
+GLOO_ON_GPU0 = {"BENCH_DIST_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def _check_two_rank_line(d, cps):
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["value"] == d["value"] and d["value"] != float("inf")
+    # N > 1: the headline is the 64x36 clip (BASELINE configs[3]); whole-job frames / max-rank time
+    assert d["config"]["frames_per_clip"] == 64 and d["config"]["boxes_per_frame"] == 36
+    assert abs(d["value"] - 2 * cps * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert len(d["repeats"]) == 2 and min(d["repeats"]) <= d["value"] <= max(d["repeats"])
+    assert d["allgather_ms"] > 0 and d["allgather_bytes_per_rank"] == cps * 2240 * 26 * 4
+    assert "scaling_note" in d and "rank(s)" in d["config"]["sharding"]
+    # what RCCL (here: gloo) saw
+    assert d["ranks_seen"] == 2 and [x["rank"] for x in d["devices"]] == [0, 1]
+    assert all(x["device"] == 0 and x["pci_bus_id"] for x in d["devices"])         # both ranks forced onto GPU 0 ...
+    assert d["distinct_devices"] == 1 and d["devices"][0]["pid"] != d["devices"][1]["pid"]   # ... as two processes
+    assert d["one_rank_alone"]["value"] > 0
+    w = d["workloads"]["16x12"]                                    # configs[1]'s clip rides along
+    assert w["value"] > 0 and w["config"]["frames_per_clip"] == 16 and w["allgather_ms"] > 0
+    # strong scaling: fixed clip sets sharded over the two ranks, scored on rank 0
+    for key, clips in (("64x36_x64", 6), ("ag_split_shaped", 40)):
+        b = d["strong_scaling"][key]
+        assert b["clips"] == clips and b["ranks"] == 2 and b["value"] > 0 and b["lpt_imbalance"] >= 1.0
+        assert [x["rank"] for x in b["per_rank"]] == [0, 1] and sum(x["clips"] for x in b["per_rank"]) == clips
+        assert sum(x["frames"] for x in b["per_rank"]) == b["frames"] and all(x["busy_s"] > 0 for x in b["per_rank"])
+        assert set(b["recall_with_constraint"]) == {"10", "20", "50"}
+
+
+SMALL = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--clips-per-step", "2",
+         "--strong-clips", "6", "--ag-clips", "40"]
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher and WORLD_SIZE unset: bench.py starts its ranks itself"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, cwd=ROOT, env=dict(env, **GLOO_ON_GPU0),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_two_rank_line(json.loads(lines[0]), 2)
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # more ranks than GPUs and nothing forcing them onto one device: refused before any child starts
+    env.pop("BENCH_FORCE_DEVICE", None)
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + SMALL, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_two_ranks_gloo_on_one_gpu():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-              "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
-              "--no-cpu-baseline", "--no-roofline", "--clips-per-step", "4"],
-             {"BENCH_DIST_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["value"] == d["value"] and d["value"] != float("inf")
-    assert abs(d["value"] - 2 * 4 * 16 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job frames / max-rank time
-    assert d["allgather_ms"] > 0 and d["allgather_bytes_per_rank"] == 4 * 176 * 26 * 4
-    assert "scaling_note" in d and "rank(s)" in d["config"]["sharding"]
-    w = d["workloads"]["64x36"]                                    # north_star's scaling workload rides along
-    assert w["value"] > 0 and w["config"]["frames_per_clip"] == 64 and w["allgather_ms"] > 0
+              "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + SMALL, GLOO_ON_GPU0)
+    _check_two_rank_line(d, 2)
 
 
 def test_bench_default_line_shape():
@@ -52,10 +105,15 @@ def test_bench_default_line_shape():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"])
+    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--ag-clips", "256",
+              "--strong-clips", "8"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "one_clip_per_pass", "workloads"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "one_clip_per_pass", "workloads", "repeats",
+              "ranks_seen", "devices", "distinct_devices", "strong_scaling"):
         assert k in d, k
+    assert d["config"]["frames_per_clip"] == 16 and d["ranks_seen"] == 1 and d["distinct_devices"] == 1
+    assert len(d["repeats"]) == 3 and sorted(d["repeats"])[1] == d["value"]
+    assert d["roofline"]["traffic_measured_in_run"] is False
     r = d["roofline"]
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     assert r["by_kernel"] and r["by_shape"]
@@ -66,12 +124,15 @@ def test_bench_default_line_shape():
     gf = sum(x["gflop_per_step"] for x in gemm_rows)
     assert abs(gf / ms - r["achieved"]) < 1e-6 * r["achieved"]        # GFLOP per ms = TFLOP/s
     w = d["workloads"]["64x36"]
-    assert w["value"] > 0 and w["roofline"]["frac"] > 0 and w["roofline"]["by_kernel"]
+    assert w["value"] > 0 and w["roofline"]["frac"] > 0 and w["roofline"]["by_kernel"] and w["one_clip_per_pass"]["value"] > 0
     # BASELINE configs[4] (DSG-DETR) and the configs[2] stand-in ride in the same line
     g = d["workloads"]["dsgdetr_16x12"]
     assert "error" not in g and g["value"] > 0 and g["roofline"]["frac"] > 0
     a = d["workloads"]["ag_split_shaped"]
     assert "error" not in a and a["value"] > 0 and a["clips"] == 256 and a["frames"] > 5000
+    assert a is not None and d["strong_scaling"]["ag_split_shaped"]["clips"] == 256
+    s64 = d["strong_scaling"]["64x36_x64"]
+    assert "error" not in s64 and s64["clips"] == 8 and s64["frames"] == 8 * 64 and s64["ranks"] == 1 and s64["lpt_imbalance"] == 1.0
     # --profile-only-batch: nothing but warm-up + timed steps
     p = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
     assert "roofline" not in p and "workloads" not in p and "one_clip_per_pass" not in p and "cpu_baseline" not in p

@@ -64,7 +64,7 @@ def test_gemm_tiles(lib, M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K", [(2, 3872, 1936), (33, 70, 100), (330, 5808, 1936), (257, 129, 36), (300, 26, 1936),
                                    (2816, 1936, 1936), (64, 64, 32), (5280, 1936, 2048), (200, 1024, 2376)])
-@pytest.mark.parametrize("tile", [0, 1, 3, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 def test_gemm_padded_path(lib, M, N, K, tile):
     """the product path: rows padded to a multiple of 32 columns, W zero there, A holding arbitrary finite values there
     (they must not reach the result), no zero-select in the kernel, loads two K-steps ahead"""
@@ -85,10 +85,9 @@ def test_gemm_padded_path(lib, M, N, K, tile):
     assert (Cc.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
 
 
-@pytest.mark.parametrize("tile", [1, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_gemm_padded_path_gathered_rows(lib, tile):
-    """A rows gathered through an index (subj/obj FC, last-decoder-layer row pruning) on the register-staged and on the
-    LDS-DMA engine (tiles 6..9: per-lane source addresses, XOR-swizzled unpadded LDS rows, 16-byte vector epilogue)"""
+    """A rows gathered through an index (subj/obj FC, last-decoder-layer row pruning), every tile"""
     g = torch.Generator(device="cuda").manual_seed(40 + tile)
     M, N, K, R = 700, 1936, 1936, 300
     Kp = (K + 31) // 32 * 32
@@ -105,9 +104,9 @@ def test_gemm_padded_path_gathered_rows(lib, tile):
     assert (Cc.double() - ref).abs().max().item() < 2e-4
 
 
-def test_gemm_engines_agree_bitwise(lib):
-    """same MFMA instruction, same k order inside every accumulator: a whole (un-split) tile gives bit-identical values
-    on both engines (M, N chosen so that no tile is stream-K split: 2 x 2 tiles of 128 x 128)"""
+def test_gemm_tiles_agree(lib):
+    """same MFMA instruction, same k order inside every accumulator whatever the tile: two tiles differ only by where the
+    stream-K schedule splits K (rounding-level agreement)"""
     g = torch.Generator(device="cuda").manual_seed(77)
     M, N, K = 256, 256, 1936
     Kp = (K + 31) // 32 * 32
@@ -115,7 +114,7 @@ def test_gemm_engines_agree_bitwise(lib):
     W = torch.zeros(N, Kp, device="cuda")
     W[:, :K] = torch.randn(N, K, device="cuda", generator=g)
     outs = []
-    for tile in (3, 9):          # 64x64 tiles on both engines: 16 tiles, far fewer than workgroups -> all split the same way?
+    for tile in (3, 2):
         Cc = torch.empty(M, N, device="cuda")
         assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(W), Kp, None, None, _p(Cc), M, N, K, 0, tile, None) == 0
         outs.append(Cc)

@@ -35,9 +35,12 @@ OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
 ATT = [f"att{i}" for i in range(3)]; SPA = [f"spa{i}" for i in range(6)]; CON = [f"con{i}" for i in range(17)]
 
 
-def make_clip(rng, gen, T, dev):
-    """One PredCls entry on the device + its packed ground truth (host arrays)."""
-    counts = rng.integers(1, 7, T).astype(np.int32)
+def make_clip(rng, gen, T, dev, counts=None, features=True):
+    """One PredCls entry on the device + its packed ground truth (host arrays).  `counts` = pairs per frame (default:
+    1..6 at random, the Action Genome range); `features=False` builds only the small tensors (boxes, labels, pair_idx,
+    im_idx, scores) -- what a rank that only EVALUATES a clip needs (bench.py's strong-scaling block); the host-side
+    random stream is consumed identically either way, so the metadata of a clip does not depend on it."""
+    counts = (rng.integers(1, 7, T) if counts is None else np.asarray(counts)).astype(np.int32)
     B, P = int(T + counts.sum()), int(counts.sum())
     frame_of_box = np.repeat(np.arange(T), counts + 1)
     first = np.concatenate(([0], np.cumsum(counts + 1)[:-1]))             # the person box of each frame
@@ -50,10 +53,11 @@ def make_clip(rng, gen, T, dev):
     im_idx = frame_of_box[obj_rows].astype(np.float32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     entry = {"boxes": t(boxes), "labels": t(labels.astype(np.int64)), "scores": torch.ones(B, device=dev),
-             "pair_idx": t(pair_idx), "im_idx": t(im_idx), "frame_counts": counts, "num_frames": int(T),
-             "features": torch.randn(B, 2048, device=dev, generator=gen),
-             "union_feat": torch.randn(P, 2048, 7, 7, device=dev, generator=gen)}
-    _, entry["spatial_masks"] = union_boxes_and_masks(entry["boxes"], entry["pair_idx"], entry["im_idx"])
+             "pair_idx": t(pair_idx), "im_idx": t(im_idx), "frame_counts": counts, "num_frames": int(T)}
+    if features:
+        entry["features"] = torch.randn(B, 2048, device=dev, generator=gen)
+        entry["union_feat"] = torch.randn(P, 2048, 7, 7, device=dev, generator=gen)
+        _, entry["spatial_masks"] = union_boxes_and_masks(entry["boxes"], entry["pair_idx"], entry["im_idx"])
     # ground truth: the detector boxes, one attention + 1..2 spatial + 1..2 contacting relations per object
     rels, rel_off = [], [0]
     for f in range(T):
