@@ -63,9 +63,21 @@ typedef struct SttranConfig {
  * pointers to contiguous row-major fp32 / int64 data; counts are host values.
  * A call may carry several clips back to back (num_clips > 1): frames are then numbered
  * consecutively over the whole batch and temporal windows never span a clip boundary.  With
- * num_clips == 1 this is exactly one reference call. */
+ * num_clips == 1 this is exactly one reference call.
+ *
+ * Two ways to hand over a batch of clips:
+ *  (1) contiguous: the seven tensor pointers below, every clip's rows concatenated (pair_idx holding batch-global box
+ *      rows) -- what `pack_clips(entries)` builds by copying;
+ *  (2) per-clip pointer tables (clip_union_feat != NULL): HOST arrays of num_clips DEVICE pointers, each clip's tensors
+ *      exactly as its producer left them -- the reference's producer hands over one clip's `entry` at a time
+ *      (tools/test_STTran.py:81-84, dataloader/wk_action_genome.py:622-627), so a batch of them is a list of separate
+ *      allocations; nothing is copied or concatenated, the kernels resolve pair -> clip through a prefix table.  In this
+ *      form every clip's pair_idx holds box rows LOCAL to that clip (its own, unmodified tensor), num_boxes / num_pairs are
+ *      the totals, clip_num_boxes / clip_num_pairs the per-clip sizes, frame_counts is required (im_idx is not read), and
+ *      the seven contiguous pointers are ignored.  Outputs are contiguous over the batch either way (clip c's rows start at
+ *      the sum of the pair counts of the clips before it).  `pack_clips(entries, copy=False)` builds this form. */
 typedef struct SttranInputs {
-  uint32_t struct_size;          /* = sizeof(SttranInputs) */
+  uint32_t struct_size;          /* = sizeof(SttranInputs), or STTRAN_INPUTS_V1_SIZE (the form without the tables) */
   int32_t num_clips;             /* >= 1 */
   int64_t num_boxes;             /* B */
   int64_t num_pairs;             /* P */
@@ -81,7 +93,19 @@ typedef struct SttranInputs {
   const void* im_idx;            /* [P] frame id of each pair, sorted ascending      */
   const float* boxes;            /* [B, 5] sgdet only        entry['boxes']          */
   const float* distribution;     /* [B, num_obj_classes-1] sgdet only                */
+  /* ---- form (2): per-clip pointer tables, HOST arrays of num_clips device pointers (all NULL in form 1) ---- */
+  const float* const* clip_features;        /* -> [B_c, feat_dim]           (16-byte aligned) */
+  const int64_t* const* clip_pair_idx;      /* -> [P_c, 2] box rows local to clip c            */
+  const int64_t* const* clip_labels;        /* -> [B_c]                                        */
+  const float* const* clip_union_feat;      /* -> [P_c, feat_dim, 7, 7]                        */
+  const float* const* clip_spatial_masks;   /* -> [P_c, 2, 27, 27]                             */
+  const float* const* clip_boxes;           /* -> [B_c, 5]                  sgdet only         */
+  const float* const* clip_distribution;    /* -> [B_c, num_obj_classes-1]  sgdet only         */
+  const int64_t* clip_num_boxes;            /* HOST [num_clips] B_c, summing to num_boxes      */
+  const int64_t* clip_num_pairs;            /* HOST [num_clips] P_c, summing to num_pairs; a clip's P_c must equal the
+                                               sum of its frames' frame_counts                 */
 } SttranInputs;
+#define STTRAN_INPUTS_V1_SIZE 112u  /* offsetof(SttranInputs, clip_features): callers built against the round-2 header */
 
 /* Tensors STTran.forward writes into `entry` (lib/sttran.py:404-409, :182).  Caller-allocated
  * device buffers.  The three *_tap pointers are optional (NULL) stage outputs for parity tests. */

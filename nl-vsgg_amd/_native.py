@@ -37,7 +37,16 @@ class SttranInputs(C.Structure):
                 ("clip_num_frames", C.POINTER(C.c_int32)), ("frame_counts", C.POINTER(C.c_int32)),
                 ("features", C.c_void_p), ("pair_idx", C.c_void_p), ("labels", C.c_void_p),
                 ("union_feat", C.c_void_p), ("spatial_masks", C.c_void_p), ("im_idx", C.c_void_p),
-                ("boxes", C.c_void_p), ("distribution", C.c_void_p)]
+                ("boxes", C.c_void_p), ("distribution", C.c_void_p),
+                # per-clip pointer tables (host arrays of device pointers), include/sttran_hip.h form (2)
+                ("clip_features", C.POINTER(C.c_void_p)), ("clip_pair_idx", C.POINTER(C.c_void_p)),
+                ("clip_labels", C.POINTER(C.c_void_p)), ("clip_union_feat", C.POINTER(C.c_void_p)),
+                ("clip_spatial_masks", C.POINTER(C.c_void_p)), ("clip_boxes", C.POINTER(C.c_void_p)),
+                ("clip_distribution", C.POINTER(C.c_void_p)),
+                ("clip_num_boxes", C.POINTER(C.c_int64)), ("clip_num_pairs", C.POINTER(C.c_int64))]
+
+
+INPUTS_V1_SIZE = 112       # STTRAN_INPUTS_V1_SIZE: the struct without the pointer tables (round-2 callers)
 
 
 class SttranOutputs(C.Structure):

@@ -67,6 +67,7 @@ hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const int64_t* u_
 // the chunk's boxes.
 struct ChunkTable {
   int n;
+  int base;                     // first chunk with pairs: per-pair offsets are relative to ITS features / union_feat / masks
   const int64_t* pair_start;
   const int64_t* box_start;
   const void* const* features;

@@ -52,11 +52,11 @@ pair_prep_kernel(ChunkTable tab, int P, int feat_dim, int num_classes, const flo
   ls = min(max(ls, (int64_t)0), (int64_t)num_classes - 1);
   lo = min(max(lo, (int64_t)0), (int64_t)num_classes - 1);
   if (threadIdx.x == 0) {
-    const int64_t f0 = float_distance(tab.features[c], tab.features[0]);
+    const int64_t f0 = float_distance(tab.features[c], tab.features[tab.base]);
     feat_off[p] = f0 + s * feat_dim;
     feat_off[(int64_t)P + p] = f0 + o * feat_dim;
-    union_off[p] = float_distance(tab.union_feat[c], tab.union_feat[0]) + lp * ((int64_t)feat_dim * 49);
-    mask_off[p] = float_distance(tab.masks[c], tab.masks[0]) + lp * 1458;
+    union_off[p] = float_distance(tab.union_feat[c], tab.union_feat[tab.base]) + lp * ((int64_t)feat_dim * 49);
+    mask_off[p] = float_distance(tab.masks[c], tab.masks[tab.base]) + lp * 1458;
     if (cls_of_pair) { cls_of_pair[p] = (int)lo; subj_of_pair[p] = (int)(tab.box_start[c] + s); }
     if (bad) atomicOr(err_flag, 1);
   }

@@ -54,10 +54,10 @@ hipError_t gemm_linear_x3(hipStream_t s, const GemmOperand& A, const void* plane
 
 // union_func1 on the bf16x3 engine: M = 49 P rows (pair, hw) read in place from the NCHW tensor (A_UNION_FLAT),
 // N = 256 out channels from the pre-split weight planes [3][256][K], all of them in one 128x256 tile (U is staged once)
-hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const void* planes, const float* bias, float* V, int P, int K,
-                                float* slab) {
+hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const int64_t* u_off, const void* planes, const float* bias,
+                                float* V, int P, int K, float* slab) {
   if (K % kBK != 0 || P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16(planes)) return hipErrorInvalidValue;
-  GemmOperand A{U, (int64_t)K * kUHW, nullptr, P};
+  GemmOperand A{U, (int64_t)K * kUHW, nullptr, P, u_off};
   X3Weights B{reinterpret_cast<const __bf16*>(planes), (int64_t)K, (int64_t)256 * K};
   EpiUnionRows epi{V, bias, 256};
   return launch_x3<X3Tile<128, 256, 2, 4, A_UNION_FLAT>, EpiUnionRows>(s, A, B, P * kUHW, 256, K, slab, epi);

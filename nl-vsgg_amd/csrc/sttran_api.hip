@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -84,6 +85,8 @@ struct SttranHandle {
   int64_t capP = 0, capB = 0;
   DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
   DevBuf dsg;                   // DSG-DETR: class-sequence tables built on the device (launch_dsg_layout)
+  DevBuf ctab, poff;            // chunk table of the call's inputs (kernels.h ChunkTable); per-pair element offsets [4 P] int64
+  std::vector<int64_t> ctab_host;   // what ctab holds (re-uploaded only when a call's pointers / sizes differ)
   int* err_flag = nullptr;
   // index-map staging (pinned) + cache of the last layout
   static constexpr int kStages = 4;
@@ -354,7 +357,8 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   HIPCK(h->uni.ensure((size_t)(cp + tok) * LD * 4));
   HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
   HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
-  HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + (size_t)cp * 2 * 4 + 4096));
+  HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + 4096));
+  HIPCK(h->poff.ensure((size_t)cp * 4 * 8));
   if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
     HIPCK(h->zbuf.ensure((size_t)cb * pad32(h->cfg.feat_dim + 328) * 4));
     HIPCK(h->hobj.ensure((size_t)cb * 1024 * 4));
@@ -362,6 +366,24 @@ int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
   h->capP = cp;
   h->capB = cb;
   h->cached_P = -1;     // the index buffer may have been re-allocated (and zeroed): the cached layout is gone
+  return STTRAN_OK;
+}
+
+// Small host tables (index maps, the chunk table) go to the device through a ring of pinned staging buffers: the
+// copy is enqueue-only, and a slot is reused only after the copy that read it has completed.
+int upload_staged(SttranHandle* h, hipStream_t s, const void* src, size_t bytes, void* dst) {
+  const int k = h->stage_next;
+  h->stage_next = (k + 1) % SttranHandle::kStages;
+  if (h->stage_ev[k]) HIPCK(hipEventSynchronize(h->stage_ev[k]));
+  else HIPCK(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
+  if (h->stage_cap[k] < bytes) {
+    if (h->stage[k]) HIPCK(hipHostFree(h->stage[k]));
+    HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->stage[k]), bytes + 4096));
+    h->stage_cap[k] = bytes + 4096;
+  }
+  memcpy(h->stage[k], src, bytes);
+  HIPCK(hipMemcpyAsync(dst, h->stage[k], bytes, hipMemcpyHostToDevice, s));
+  HIPCK(hipEventRecord(h->stage_ev[k], s));
   return STTRAN_OK;
 }
 
@@ -563,7 +585,7 @@ void sttran_destroy(SttranHandle* h) {
   }
   if (h->w4_planes) hipFree(h->w4_planes);
   for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
-                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf, &h->dsg})
+                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf, &h->dsg, &h->ctab, &h->poff})
     b->release();
   for (int i = 0; i < SttranHandle::kStages; ++i) {
     if (h->stage[i]) hipHostFree(h->stage[i]);
@@ -770,22 +792,52 @@ int sttran_profile_entries(SttranHandle* h, SttranProfEntry* out, int32_t cap, i
   return STTRAN_OK;
 }
 
-int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs* out, void* stream_) {
+int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, void* stream_) {
   if (!h) return STTRAN_ERR_INVALID;
-  if (!in || !out || in->struct_size != sizeof(SttranInputs) || out->struct_size != sizeof(SttranOutputs))
+  static_assert(offsetof(SttranInputs, clip_features) == STTRAN_INPUTS_V1_SIZE, "STTRAN_INPUTS_V1_SIZE");
+  if (!in_ || !out || (in_->struct_size != sizeof(SttranInputs) && in_->struct_size != STTRAN_INPUTS_V1_SIZE) ||
+      out->struct_size != sizeof(SttranOutputs))
     return fail(h, STTRAN_ERR_INVALID, "forward: bad struct_size");
+  SttranInputs in_copy{};                        // a round-2 caller's struct has no pointer tables: they read as NULL
+  memcpy(&in_copy, in_, in_->struct_size);
+  const SttranInputs* in = &in_copy;
   const SttranConfig& c = h->cfg;
   const int64_t P = in->num_pairs, B = in->num_boxes;
   if (P <= 0 || B <= 0) return fail(h, STTRAN_ERR_EMPTY, "forward: entry has no pairs");
   if (P > (1 << 28) / 49 || B > (1 << 30)) return fail(h, STTRAN_ERR_LIMIT, "forward: too many pairs");
-  if (!in->features || !in->pair_idx || !in->labels || !in->union_feat || !in->spatial_masks ||
-      !out->attention_distribution || !out->spatial_distribution || !out->contacting_distribution)
-    return fail(h, STTRAN_ERR_INVALID, "forward: null tensor pointer");
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
-  if (oc && (!in->boxes || !in->distribution || !out->distribution))
-    return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs boxes, distribution and an output distribution");
+  const bool tables = in->clip_union_feat != nullptr;
+  if (!out->attention_distribution || !out->spatial_distribution || !out->contacting_distribution)
+    return fail(h, STTRAN_ERR_INVALID, "forward: null output pointer");
   if (in->num_clips < 1 || (in->num_clips > 1 && !in->clip_num_frames))
     return fail(h, STTRAN_ERR_INVALID, "forward: bad clip description");
+  if (tables) {
+    if (!in->clip_features || !in->clip_pair_idx || !in->clip_labels || !in->clip_spatial_masks || !in->clip_num_boxes ||
+        !in->clip_num_pairs || (oc && (!in->clip_boxes || !in->clip_distribution)))
+      return fail(h, STTRAN_ERR_INVALID, "forward: incomplete per-clip pointer tables");
+    if (!in->frame_counts || in->num_frames <= 0)
+      return fail(h, STTRAN_ERR_INVALID, "forward: per-clip pointer tables need frame_counts");
+    int64_t tb = 0, tp = 0;
+    for (int i = 0; i < in->num_clips; ++i) {
+      const int64_t bc = in->clip_num_boxes[i], pc = in->clip_num_pairs[i];
+      if (bc < 0 || pc < 0 || (pc > 0 && bc <= 0)) return fail(h, STTRAN_ERR_INVALID, "forward: bad per-clip sizes");
+      tb += bc; tp += pc;
+      const auto mis = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; };
+      if (bc > 0 && (!in->clip_features[i] || !in->clip_labels[i] || mis(in->clip_features[i], 16) || mis(in->clip_labels[i], 8) ||
+                     (oc && (!in->clip_boxes[i] || !in->clip_distribution[i] || mis(in->clip_boxes[i], 4) || mis(in->clip_distribution[i], 4)))))
+        return fail(h, STTRAN_ERR_INVALID, "forward: null or misaligned per-clip box tensor");
+      if (pc > 0 && (!in->clip_pair_idx[i] || !in->clip_union_feat[i] || !in->clip_spatial_masks[i] || mis(in->clip_pair_idx[i], 8) ||
+                     mis(in->clip_union_feat[i], 4) || mis(in->clip_spatial_masks[i], 4)))
+        return fail(h, STTRAN_ERR_INVALID, "forward: null or misaligned per-clip pair tensor");
+    }
+    if (tb != B || tp != P) return fail(h, STTRAN_ERR_INVALID, "forward: per-clip sizes do not sum to num_boxes / num_pairs");
+  } else {
+    if (!in->features || !in->pair_idx || !in->labels || !in->union_feat || !in->spatial_masks)
+      return fail(h, STTRAN_ERR_INVALID, "forward: null tensor pointer");
+    if (oc && (!in->boxes || !in->distribution))
+      return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs boxes and distribution");
+  }
+  if (oc && !out->distribution) return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs an output distribution");
   HIPCK(hipSetDevice(c.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
   h->prof_stream = s;
@@ -854,6 +906,15 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     for (int32_t v : clips) { if (v < 0) return fail(h, STTRAN_ERR_INVALID, "forward: negative clip length"); tf += v; }
     if (tf != (int64_t)counts.size()) return fail(h, STTRAN_ERR_INVALID, "forward: clip_num_frames do not sum to num_frames");
   }
+  if (tables) {
+    size_t f = 0;
+    for (int i = 0; i < in->num_clips; ++i) {
+      int64_t pc = 0;
+      for (int j = 0; j < clips[i]; ++j) pc += counts[f++];
+      if (pc != in->clip_num_pairs[i])
+        return fail(h, STTRAN_ERR_INVALID, "forward: clip_num_pairs disagrees with the clip's frame_counts");
+    }
+  }
 
   // ---- index maps (cached while the layout repeats) -----------------------------------------
   const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
@@ -868,6 +929,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     if (dsg_dev) {
       build_layout_dsg_static(counts, clips, P, c.num_obj_classes, buf, h->lay);
     } else if (is_dsg) {
+      if (tables) return fail(h, STTRAN_ERR_INVALID, "forward: STTRAN_DSG_HOST_LAYOUT=1 reads a contiguous pair_idx (no pointer tables)");
       // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
       // second model on the shared kernels, not the latency path
       std::vector<int64_t> hp((size_t)P * 2), hl((size_t)B);
@@ -886,19 +948,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     //  layout kernel and reported by sttran_sync_check)
     if (h->lay.max_enc > kAttnMaxKeys || (!h->lay.dsg_device && h->lay.max_dec > kAttnMaxKeys))
       return fail(h, STTRAN_ERR_LIMIT, "forward: a frame/window exceeds the attention key limit");
-    const int k = h->stage_next;
-    h->stage_next = (k + 1) % SttranHandle::kStages;
-    if (h->stage_ev[k]) HIPCK(hipEventSynchronize(h->stage_ev[k]));
-    else HIPCK(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
-    if (h->stage_cap[k] < buf.size() * 4) {
-      if (h->stage[k]) HIPCK(hipHostFree(h->stage[k]));
-      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->stage[k]), buf.size() * 4 + 4096));
-      h->stage_cap[k] = buf.size() * 4 + 4096;
-    }
-    memcpy(h->stage[k], buf.data(), buf.size() * 4);
     if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
-    HIPCK(hipMemcpyAsync(h->idx.p, h->stage[k], buf.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCK(hipEventRecord(h->stage_ev[k], s));
+    if ((rc = upload_staged(h, s, buf.data(), buf.size() * 4, h->idx.p))) return rc;
     h->cached_P = host_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
   }
   const SttranHandle::Layout& L = h->lay;
@@ -909,19 +960,60 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   const uint8_t* slot = reinterpret_cast<const uint8_t*>(ib + L.o_slot);
   const int* need = ib + L.o_need; const int* qbegin = ib + L.o_qbegin;
   const int* tok0 = ib + L.o_tok0; const int* tok1 = ib + L.o_tok1;
+  int* dsg_scratch = nullptr;
   if (L.dsg_device) {
     // class sequences from labels[pair_idx[:, 1]] where they live: [dec_off | dec_len] per (clip, class) slot, then
-    // dec_src, need, out_src per token / pair, then 4 P ints of scratch
+    // dec_src, need, out_src per token / pair, then 4 P ints of scratch (launched behind pair_prep, which resolves the
+    // pairs' classes and subjects through the chunk table)
     const int64_t Kseq = L.n_dec_seq;
     HIPCK(h->dsg.ensure((size_t)(2 * Kseq + 7 * P + 64) * 4));
     int* d = h->dsg.as<int32_t>();
-    HIPCK(launch_dsg_layout(s, in->pair_idx, in->labels, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P,
-                            400, kAttnMaxKeys, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, d + 2 * Kseq + 3 * P,
-                            h->err_flag, L.max_dec));
     dec_off = d; dec_len = d + Kseq; dec_src = d + 2 * Kseq; need = d + 2 * Kseq + P; out_src = d + 2 * Kseq + 2 * P;
+    dsg_scratch = d + 2 * Kseq + 3 * P;
   }
-  int* subj_idx = h->idx.as<int32_t>() + (kIdxIntsPerPair * h->capP + 64);
-  int* obj_idx = subj_idx + h->capP;
+
+  // ---- where the inputs live: one chunk per clip (pointer tables) or one chunk for the contiguous batch ----
+  ChunkTable tab{};
+  const float *feat_base = nullptr, *union_base = nullptr, *mask_base = nullptr;
+  {
+    const int n = tables ? in->num_clips : 1;
+    std::vector<int64_t> t((size_t)(2 * (n + 1) + 7 * n), 0);
+    int64_t* pair_start = t.data(); int64_t* box_start = pair_start + n + 1; int64_t* ptr = box_start + n + 1;
+    auto put = [&](int k, int i, const void* p) { ptr[(size_t)k * n + i] = (int64_t)reinterpret_cast<intptr_t>(p); };
+    int base = -1;                                  // first chunk with pairs: the offsets are relative to ITS tensors
+    for (int i = 0; i < n; ++i) {
+      const int64_t pc = tables ? in->clip_num_pairs[i] : P, bc = tables ? in->clip_num_boxes[i] : B;
+      pair_start[i + 1] = pair_start[i] + pc; box_start[i + 1] = box_start[i] + bc;
+      if (base < 0 && pc > 0) base = i;
+      put(0, i, tables ? (const void*)in->clip_features[i] : in->features);
+      put(1, i, tables ? (const void*)in->clip_pair_idx[i] : in->pair_idx);
+      put(2, i, tables ? (const void*)in->clip_labels[i] : in->labels);
+      put(3, i, tables ? (const void*)in->clip_union_feat[i] : in->union_feat);
+      put(4, i, tables ? (const void*)in->clip_spatial_masks[i] : in->spatial_masks);
+      if (oc) {
+        put(5, i, tables ? (const void*)in->clip_boxes[i] : in->boxes);
+        put(6, i, tables ? (const void*)in->clip_distribution[i] : in->distribution);
+      }
+    }
+    if (base < 0) return fail(h, STTRAN_ERR_EMPTY, "forward: entry has no pairs");
+    feat_base = reinterpret_cast<const float*>(ptr[0 * (size_t)n + base]);
+    union_base = reinterpret_cast<const float*>(ptr[3 * (size_t)n + base]);
+    mask_base = reinterpret_cast<const float*>(ptr[4 * (size_t)n + base]);
+    if (t != h->ctab_host) {
+      h->ctab_host.clear();
+      if (h->ctab.bytes < t.size() * 8) { HIPCK(hipStreamSynchronize(s)); HIPCK(h->ctab.ensure(t.size() * 8 * 2)); }
+      if ((rc = upload_staged(h, s, t.data(), t.size() * 8, h->ctab.p))) return rc;
+      h->ctab_host = t;
+    }
+    const int64_t* d = h->ctab.as<int64_t>();
+    auto arr = [&](int k) { return reinterpret_cast<const void* const*>(d + 2 * (n + 1) + (size_t)k * n); };
+    tab.n = n; tab.base = base; tab.pair_start = d; tab.box_start = d + n + 1;
+    tab.features = arr(0); tab.pair_idx = arr(1); tab.labels = arr(2); tab.union_feat = arr(3); tab.masks = arr(4);
+    tab.boxes = arr(5); tab.dist = arr(6);
+  }
+  int64_t* feat_off = h->poff.as<int64_t>();          // [2][P] subject / object feature rows
+  int64_t* union_off = feat_off + 2 * P;              // [P]
+  int64_t* mask_off = feat_off + 3 * P;               // [P]
 
   const int D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
   const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (ensure_workspace)
@@ -938,7 +1030,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
     const int64_t ldz = pad32(zd);
     {
       ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * B * (2.0 * zd), "objcls_prep_kernel", B, zd, 0);
-      HIPCK(launch_objcls_prep(s, in->features, in->distribution, in->boxes, W(h, "object_classifier.obj_embed.weight"),
+      HIPCK(launch_objcls_prep(s, tab, W(h, "object_classifier.obj_embed.weight"),
                                h->oc_pos_scale, h->oc_pos_shift, W(h, "object_classifier.pos_embed.1.weight"),
                                W(h, "object_classifier.pos_embed.1.bias"), Z, ldz, (int)B, FD, NC - 1, 200));
     }
@@ -952,12 +1044,21 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
   // ---- pair fusion (lib/sttran.py:381-399) -> X0 [P, 1936] -----------------------------------
   {
     ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2, "pair_prep_kernel", P, 400, 0);
-    HIPCK(launch_pair_prep(s, in->pair_idx, in->labels, (int)P, (int)B, NC, W(h, "obj_embed.weight"),
-                           W(h, "obj_embed2.weight"), 200, subj_idx, obj_idx, X0, (int)LD, 1536, h->err_flag));
+    HIPCK(launch_pair_prep(s, tab, (int)P, FD, NC, W(h, "obj_embed.weight"), W(h, "obj_embed2.weight"), 200, feat_off,
+                           union_off, mask_off, dsg_scratch, dsg_scratch ? dsg_scratch + P : nullptr, X0, (int)LD, 1536,
+                           h->err_flag));
   }
-  if ((rc = run_linear(h, s, GemmOperand{in->features, FD, subj_idx}, W(h, "subj_fc.weight"), (int)P, 512, FD,
+  if (L.dsg_device) {
+    const int64_t Kseq = L.n_dec_seq;
+    int* d = h->dsg.as<int32_t>();
+    HIPCK(launch_dsg_layout(s, nullptr, nullptr, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P, 400,
+                            kAttnMaxKeys, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, dsg_scratch,
+                            h->err_flag, L.max_dec));
+  }
+  // subject / object rows of `features` gathered by element offset (one chunk per clip: GemmOperand::rowoff)
+  if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off}, W(h, "subj_fc.weight"), (int)P, 512, FD,
                        epi_plain(X0, LD, W(h, "subj_fc.bias"))))) return rc;
-  if ((rc = run_linear(h, s, GemmOperand{in->features, FD, obj_idx}, W(h, "obj_fc.weight"), (int)P, 512, FD,
+  if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off + P}, W(h, "obj_fc.weight"), (int)P, 512, FD,
                        epi_plain(X0 + 512, LD, W(h, "obj_fc.bias"))))) return rc;
   {
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
@@ -965,7 +1066,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
       // conv 7x7/2 -> ReLU -> BN -> max-pool in one kernel; the [P,128,14,14] intermediate stays on chip
       ProfScope ps(h, s, STTRAN_PROF_MASK_CONV, 2.0 * P * 128 * 196 * 98, 4.0 * P * (1458 + 128 * 49), "mask_conv1_pool_kernel",
                    128, P * 196, 98);
-      HIPCK(launch_mask_conv1_pool(s, in->spatial_masks, h->w0_perm, W(h, "conv.0.bias"), h->bn1_scale,
+      HIPCK(launch_mask_conv1_pool(s, mask_base, mask_off, h->w0_perm, W(h, "conv.0.bias"), h->bn1_scale,
                                    h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
@@ -986,9 +1087,10 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs*
                  x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_UNION_FLAT>,EpiUnionRows>"
                     : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
     if (x3)
-      HIPCK(launch_union_conv_x3(s, in->union_feat, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD, h->slab.as<float>()));
+      HIPCK(launch_union_conv_x3(s, union_base, union_off, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD,
+                                 h->slab.as<float>()));
     else
-      HIPCK(launch_union_conv(s, in->union_feat, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+      HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                               h->slab.as<float>()));
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,

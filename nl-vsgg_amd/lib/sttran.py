@@ -252,6 +252,8 @@ class STTran:
             nat.check(lib, h, lib.sttran_set_gemm_engine(h, {"fp32": 0, "bf16x3": 1}[self.gemm_engine]))
             self._engine_set = self.gemm_engine
         f32, i64 = torch.float32, torch.int64
+        if isinstance(entry, PackedClips) and entry.by_pointer:
+            return self._forward_by_pointer(entry)
         if self._select:
             from .object_classifier import sgdet_select
             entry = sgdet_select(entry)                      # lib/sttran.py:377 -> :185-283
@@ -263,13 +265,7 @@ class STTran:
         P, B = int(pair.shape[0]), int(feats.shape[0])
         if P == 0:
             raise nat.SttranError(3, "entry has no pairs")
-        # shapes the reference's layers would reject (nn.Linear / Conv2d / .view raise a RuntimeError there)
-        if (feats.dim() != 2 or feats.shape[1] != self.feat_dim or tuple(pair.shape) != (P, 2) or tuple(labels.shape) != (B,)
-                or tuple(union.shape) != (P, self.feat_dim, 7, 7) or tuple(masks.shape) != (P, 2, 27, 27)):
-            raise ValueError(
-                f"entry shapes: features {tuple(feats.shape)} (want [B,{self.feat_dim}]), pair_idx {tuple(pair.shape)} "
-                f"(want [P,2]), labels {tuple(labels.shape)} (want [B]), union_feat {tuple(union.shape)} (want "
-                f"[P,{self.feat_dim},7,7]), spatial_masks {tuple(masks.shape)} (want [P,2,27,27])")
+        self._check_shapes(feats, pair, labels, union, masks, P, B)
         im = entry["im_idx"]
         im_dtype = nat.DTYPE_I64 if (isinstance(im, torch.Tensor) and not im.dtype.is_floating_point) else nat.DTYPE_F32
         im = self._dev(im, i64 if im_dtype == nat.DTYPE_I64 else f32, "im_idx")
@@ -277,10 +273,6 @@ class STTran:
             raise ValueError(f"entry['im_idx'] has shape {tuple(im.shape)}, want [{P}]")
         counts = _host_i32(entry.get("frame_counts"))
         clips = _host_i32(entry.get("clip_num_frames"))
-        dev = feats.device
-        att = torch.empty((P, self.attention_class_num), dtype=f32, device=dev)
-        spa = torch.empty((P, self.spatial_class_num), dtype=f32, device=dev)
-        con = torch.empty((P, self.contact_class_num), dtype=f32, device=dev)
         inp = nat.SttranInputs(struct_size=C.sizeof(nat.SttranInputs),
                                num_clips=1 if clips is None else len(clips), num_boxes=B, num_pairs=P,
                                num_frames=0 if counts is None else len(counts), im_idx_dtype=im_dtype)
@@ -292,24 +284,94 @@ class STTran:
             inp.clip_num_frames = clips.ctypes.data_as(C.POINTER(C.c_int32))
         inp.features, inp.pair_idx, inp.labels = feats.data_ptr(), pair.data_ptr(), labels.data_ptr()
         inp.union_feat, inp.spatial_masks, inp.im_idx = union.data_ptr(), masks.data_ptr(), im.data_ptr()
-        out = nat.SttranOutputs(struct_size=C.sizeof(nat.SttranOutputs))
-        out.attention_distribution, out.spatial_distribution = att.data_ptr(), spa.data_ptr()
-        out.contacting_distribution = con.data_ptr()
-        keep = [feats, pair, labels, union, masks, im]
+        keep = [feats, pair, labels, union, masks, im, counts, clips]
+        dist_shape = None
         if self.mode != "predcls" and not self._select:
             boxes = self._dev(entry["boxes"], f32, "boxes")
             dist_in = self._dev(entry["distribution"], f32, "distribution")
-            # the reference multiplies distribution [B, C-1] with obj_embed.weight [C-1, 200] (lib/sttran.py:174) and
-            # would raise on anything else -- e.g. on an entry that already went through forward once, whose
-            # `distribution` now holds the [B, C] logits (:182)
-            if tuple(dist_in.shape) != (B, len(self.obj_classes) - 1) or tuple(boxes.shape) != (B, 5):
-                raise ValueError(f"entry['distribution'] {tuple(dist_in.shape)} / entry['boxes'] {tuple(boxes.shape)}: "
-                                 f"want [{B},{len(self.obj_classes) - 1}] and [{B},5] (was this entry already forwarded?)")
-            if "scores" not in entry or tuple(entry["scores"].shape) != (B,):
-                raise ValueError(f"entry['scores'] must be a [{B}] tensor in sgdet mode (lib/sttran.py:184)")
-            dist_out = torch.empty((B, len(self.obj_classes)), dtype=f32, device=dev)
-            inp.boxes, inp.distribution, out.distribution = boxes.data_ptr(), dist_in.data_ptr(), dist_out.data_ptr()
+            self._check_sgdet(entry, boxes, dist_in, B)
+            inp.boxes, inp.distribution = boxes.data_ptr(), dist_in.data_ptr()
             keep += [boxes, dist_in]
+            dist_shape = (B, len(self.obj_classes))
+        return self._run(entry, inp, P, dist_shape, feats.device, keep)
+
+    def _check_shapes(self, feats, pair, labels, union, masks, P, B, where="entry"):
+        # shapes the reference's layers would reject (nn.Linear / Conv2d / .view raise a RuntimeError there)
+        if (feats.dim() != 2 or feats.shape[1] != self.feat_dim or tuple(pair.shape) != (P, 2) or tuple(labels.shape) != (B,)
+                or tuple(union.shape) != (P, self.feat_dim, 7, 7) or tuple(masks.shape) != (P, 2, 27, 27)):
+            raise ValueError(
+                f"{where} shapes: features {tuple(feats.shape)} (want [B,{self.feat_dim}]), pair_idx {tuple(pair.shape)} "
+                f"(want [P,2]), labels {tuple(labels.shape)} (want [B]), union_feat {tuple(union.shape)} (want "
+                f"[P,{self.feat_dim},7,7]), spatial_masks {tuple(masks.shape)} (want [P,2,27,27])")
+
+    def _check_sgdet(self, entry, boxes, dist_in, B):
+        # the reference multiplies distribution [B, C-1] with obj_embed.weight [C-1, 200] (lib/sttran.py:174) and
+        # would raise on anything else -- e.g. on an entry that already went through forward once, whose
+        # `distribution` now holds the [B, C] logits (:182)
+        if tuple(dist_in.shape) != (B, len(self.obj_classes) - 1) or tuple(boxes.shape) != (B, 5):
+            raise ValueError(f"entry['distribution'] {tuple(dist_in.shape)} / entry['boxes'] {tuple(boxes.shape)}: "
+                             f"want [{B},{len(self.obj_classes) - 1}] and [{B},5] (was this entry already forwarded?)")
+        if "scores" not in entry or tuple(entry["scores"].shape) != (B,):
+            raise ValueError(f"entry['scores'] must be a [{B}] tensor in sgdet mode (lib/sttran.py:184)")
+
+    def _forward_by_pointer(self, packed):
+        """A batch of clips handed over as per-clip pointer tables (`pack_clips(entries, copy=False)`): every clip's
+        tensors stay where its producer left them (include/sttran_hip.h, SttranInputs form 2)."""
+        if self._select:
+            raise NotImplementedError("sgdet without weak supervision selects boxes per clip: forward the clips one by one "
+                                      "or pack the selected entries")
+        lib, f32, i64 = self._lib, torch.float32, torch.int64
+        clips = packed.clips
+        n = len(clips)
+        sg = self.mode != "predcls"
+        names = ["features", "pair_idx", "labels", "union_feat", "spatial_masks"] + (["boxes", "distribution"] if sg else [])
+        tabs = {k: (C.c_void_p * n)() for k in names}
+        nb, npairs = (C.c_int64 * n)(), (C.c_int64 * n)()
+        keep = [tabs, nb, npairs]
+        for i, e in enumerate(clips):
+            feats = self._dev(e["features"], f32, "features")
+            pair = self._dev(e["pair_idx"], i64, "pair_idx")
+            labels = self._dev(e["labels"], i64, "labels")
+            union = self._dev(e["union_feat"], f32, "union_feat")
+            masks = self._dev(e["spatial_masks"], f32, "spatial_masks")
+            Pc, Bc = int(pair.shape[0]), int(feats.shape[0])
+            self._check_shapes(feats, pair, labels, union, masks, Pc, Bc, where=f"clip {i}")
+            ts = [feats, pair, labels, union, masks]
+            if sg:
+                boxes = self._dev(e["boxes"], f32, "boxes")
+                dist_in = self._dev(e["distribution"], f32, "distribution")
+                self._check_sgdet(e, boxes, dist_in, Bc)
+                ts += [boxes, dist_in]
+            for k, t in zip(names, ts):
+                tabs[k][i] = t.data_ptr()
+            nb[i], npairs[i] = Bc, Pc
+            keep.append(ts)
+        P, B = int(sum(packed["_pairs_per_clip"])), int(sum(packed["_boxes_per_clip"]))
+        if P == 0:
+            raise nat.SttranError(3, "entry has no pairs")
+        counts, cl = packed["frame_counts"], packed["clip_num_frames"]
+        inp = nat.SttranInputs(struct_size=C.sizeof(nat.SttranInputs), num_clips=n, num_boxes=B, num_pairs=P,
+                               num_frames=len(counts), im_idx_dtype=nat.DTYPE_F32)
+        inp.frame_counts = counts.ctypes.data_as(C.POINTER(C.c_int32))
+        inp.clip_num_frames = cl.ctypes.data_as(C.POINTER(C.c_int32))
+        for k in names:
+            setattr(inp, "clip_" + k, tabs[k])
+        inp.clip_num_boxes, inp.clip_num_pairs = nb, npairs
+        keep += [counts, cl]
+        return self._run(packed, inp, P, (B, len(self.obj_classes)) if sg else None, torch.device("cuda", self._device), keep)
+
+    def _run(self, entry, inp, P, dist_shape, dev, keep):
+        lib, h, f32 = self._lib, self._handle, torch.float32
+        att = torch.empty((P, self.attention_class_num), dtype=f32, device=dev)
+        spa = torch.empty((P, self.spatial_class_num), dtype=f32, device=dev)
+        con = torch.empty((P, self.contact_class_num), dtype=f32, device=dev)
+        out = nat.SttranOutputs(struct_size=C.sizeof(nat.SttranOutputs))
+        out.attention_distribution, out.spatial_distribution = att.data_ptr(), spa.data_ptr()
+        out.contacting_distribution = con.data_ptr()
+        dist_out = None
+        if dist_shape is not None:
+            dist_out = torch.empty(dist_shape, dtype=f32, device=dev)
+            out.distribution = dist_out.data_ptr()
         taps = {}
         if self.taps:
             for k in ("rel_features", "local_output", "global_output"):
@@ -317,14 +379,17 @@ class STTran:
                 setattr(out, k + "_tap", taps[k].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
         nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
+        del keep                                             # (the launches read device memory that `entry` keeps alive)
         if self.check_indices:
             self.sync_check()
         # ---- the keys the reference writes (lib/sttran.py:91,182-184,404-409) ----
-        if not self._select:
+        lazy = isinstance(entry, PackedClips) and entry.by_pointer    # `pred_labels` / `pred_scores` alias on first access
+        if not self._select and not lazy:
             entry["pred_labels"] = entry["labels"]
-        if self.mode != "predcls" and not self._select:
+        if dist_out is not None:
             entry["distribution"] = dist_out
-            entry["pred_scores"] = entry["scores"]
+            if not lazy:
+                entry["pred_scores"] = entry["scores"]
         entry["attention_distribution"] = att
         entry["spatial_distribution"] = spa
         entry["contacting_distribution"] = con
@@ -333,37 +398,77 @@ class STTran:
         return entry
 
 
-def pack_clips(entries):
-    """Concatenate several clips into one `entry` the HIP path processes in a single pass.
+class PackedClips(dict):
+    """What `pack_clips` returns: a batch of clips as ONE entry.  With `copy=False` (`by_pointer`) the big tensors are
+    NOT concatenated -- `clips` keeps the original per-clip dicts and the model hands their pointers to the library --;
+    the small batch-level tensors a consumer of the predictions may ask for (`pair_idx` with batch-global box rows,
+    `im_idx` with batch-global frame ids, `labels`, `boxes`, `scores`, `distribution`: a few KB per clip) are
+    concatenated on first access (`packed["pair_idx"]`), so a forward that nobody scores never builds them."""
 
-    Frames are renumbered consecutively, box rows of `pair_idx` are offset, and the host-side
-    `clip_num_frames` / `frame_counts` hints are attached so temporal windows stop at clip borders
-    (no reference counterpart: the reference batch is one clip, dataloader/wk_action_genome.py:622-627).
-    Use `unpack_predictions` to split the outputs again."""
-    cat = {}
-    box_off = frame_off = 0
-    pair, im, counts, clips = [], [], [], []
+    SMALL = ("labels", "boxes", "scores", "distribution", "pair_idx", "im_idx")
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.clips = None
+        self.by_pointer = False
+
+    def __missing__(self, key):
+        if self.by_pointer and key in ("pred_labels", "pred_scores"):          # lib/sttran.py:91,184: aliases of the inputs
+            return self[key[5:]]
+        if not self.by_pointer or key not in self.SMALL or not all(key in e for e in self.clips):
+            raise KeyError(key)
+        if key == "pair_idx":
+            offs = np.concatenate(([0], np.cumsum(self["_boxes_per_clip"])[:-1]))
+            v = torch.cat([e["pair_idx"] + int(o) for e, o in zip(self.clips, offs)], dim=0)
+        elif key == "im_idx":
+            offs = np.concatenate(([0], np.cumsum(self["clip_num_frames"])[:-1]))
+            v = torch.cat([e["im_idx"] + int(o) for e, o in zip(self.clips, offs)], dim=0)
+        else:
+            v = torch.cat([e[key] for e in self.clips], dim=0)
+        self[key] = v
+        return v
+
+
+def pack_clips(entries, copy=True):
+    """Several clips as one `entry` the HIP path processes in a single pass.
+
+    Frames are renumbered consecutively and the host-side `clip_num_frames` / `frame_counts` hints are attached so
+    temporal windows stop at clip borders (no reference counterpart: the reference batch is one clip,
+    dataloader/wk_action_genome.py:622-627).  `copy=True` concatenates every tensor (box rows of `pair_idx` offset):
+    one contiguous entry, at the price of a device-to-device copy of all inputs (4.7 GB for 64 clips of 16x12).
+    `copy=False` copies NOTHING: the clips' tensors stay where they are and the library reads them through per-clip
+    pointer tables (include/sttran_hip.h, SttranInputs form 2); the entries must stay alive and unmodified until the
+    forward has run.  Use `unpack_predictions` to split the outputs again."""
+    entries = list(entries)
+    cat = PackedClips()
+    counts, clips = [], []
     for e in entries:
         fc = _host_i32(e.get("frame_counts"))
         if fc is None:
             fr = e["im_idx"].detach().cpu().numpy().astype(np.int64)
-            fc = np.bincount(fr, minlength=int(e.get("num_frames", fr[-1] + 1))).astype(np.int32)
-        pair.append(e["pair_idx"] + box_off)
-        im.append(e["im_idx"] + frame_off)
+            fc = np.bincount(fr, minlength=int(e.get("num_frames", (fr[-1] + 1) if len(fr) else 0))).astype(np.int32)
         counts.append(fc)
         clips.append(len(fc))
+    cat["frame_counts"] = np.concatenate(counts) if counts else np.zeros(0, np.int32)
+    cat["clip_num_frames"] = np.asarray(clips, dtype=np.int32)
+    cat["num_frames"] = int(sum(clips))
+    cat["_pairs_per_clip"] = [int(e["pair_idx"].shape[0]) for e in entries]
+    cat["_boxes_per_clip"] = [int(e["labels"].shape[0]) for e in entries]
+    if not copy:
+        cat.clips, cat.by_pointer = entries, True
+        return cat
+    box_off = frame_off = 0
+    pair, im = [], []
+    for e, nf in zip(entries, clips):
+        pair.append(e["pair_idx"] + box_off)
+        im.append(e["im_idx"] + frame_off)
         box_off += int(e["labels"].shape[0])
-        frame_off += len(fc)
+        frame_off += nf
     for k in ("features", "labels", "union_feat", "spatial_masks", "boxes", "scores", "distribution"):
         if all(k in e for e in entries):
             cat[k] = torch.cat([e[k] for e in entries], dim=0)
     cat["pair_idx"] = torch.cat(pair, dim=0)
     cat["im_idx"] = torch.cat(im, dim=0)
-    cat["frame_counts"] = np.concatenate(counts)
-    cat["clip_num_frames"] = np.asarray(clips, dtype=np.int32)
-    cat["num_frames"] = int(frame_off)
-    cat["_pairs_per_clip"] = [int(e["pair_idx"].shape[0]) for e in entries]
-    cat["_boxes_per_clip"] = [int(e["labels"].shape[0]) for e in entries]
     return cat
 
 

@@ -126,16 +126,52 @@ def test_gatherer_rejects_overflow():
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         g = PredictionGatherer(rows_cap=4, clips_cap=2, cols=26)
+        # capacities are rank-local: an overflowing rank still takes part in the collective and the error is raised
+        # where the result is read (by every rank), not before the all-gather
         with pytest.raises(ValueError):
-            g.submit(torch.zeros(5, 26), [0], [5])
+            g.result(g.submit(torch.zeros(5, 26), [0], [5]))
         with pytest.raises(ValueError):
-            g.submit(torch.zeros(3, 26), [0, 1, 2], [1, 1, 1])
+            g.result(g.submit(torch.zeros(3, 26), [0, 1, 2], [1, 1, 1]))
         with pytest.raises(ValueError):
-            g.submit(torch.zeros(3, 26), [0], [2])
+            g.submit(torch.zeros(3, 26), [0], [2])                   # inconsistent arguments: a caller bug, raised at once
         got = g.result(g.submit(torch.ones(3, 26), [7], [3]))
         assert list(got) == [7] and torch.equal(got[7], torch.ones(3, 26))
     finally:
         dist.destroy_process_group()
+
+
+def _worker_overflow(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = PredictionGatherer(rows_cap=4, clips_cap=2, cols=26)
+        n = 6 if rank == 1 else 2                                     # rank 1 alone exceeds rows_cap
+        t = g.submit(torch.ones(n, 26), [rank], [n])                  # must not raise before the collective (rank 0 would hang)
+        try:
+            g.result(t)
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "rank 1" in str(e)))
+        # the gatherer stays usable
+        got = g.result(g.submit(torch.full((2, 26), float(rank)), [rank], [2]))
+        q.put((rank, sorted(got) == [0, 1] and all(torch.equal(got[r], torch.full((2, 26), float(r))) for r in (0, 1))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_overflow_on_one_rank_is_seen_by_all_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in range(4)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok is True for _, ok in res), res
 
 
 def test_assign_clips_balances_and_is_deterministic():

@@ -147,6 +147,101 @@ def test_packed_clips_equal_single_clips(predcls):
             np.testing.assert_allclose(many[k].cpu().numpy(), one[k], atol=2e-5, rtol=0)
 
 
+RAGGED_BATCH = [[2, 3, 1], [4], [1, 0, 2, 2], [3, 3], [0, 5, 0, 0, 2], [7, 1]]
+
+
+@pytest.mark.parametrize("mode", ["predcls", "sgdet"])
+def test_packed_by_pointer_equals_packed_by_copy(mode, predcls, sgdet):
+    """`pack_clips(entries, copy=False)`: the clips' tensors stay where they are (per-clip pointer tables, pair_idx rows
+    local to each clip) -- the SAME batch as the concatenated form, so every output and stage tensor is bit-identical
+    to it, and each clip agrees with its single-clip forward to rounding (another tile plan)."""
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    model = sgdet if mode == "sgdet" else predcls
+    kw = dict(mode="sgdet", im_idx_dtype=np.int64) if mode == "sgdet" else {}
+    clips = [_cuda_entry(syn.make_entry(150 + i, c, **kw)) for i, c in enumerate(RAGGED_BATCH)]
+    keys = OUT_KEYS + (("distribution",) if mode == "sgdet" else ())
+    model.taps = True
+    try:
+        by_copy = model(pack_clips([dict(e) for e in clips]))
+        ref = {k: by_copy[k].cpu().numpy() for k in keys + tuple("_tap_" + t for t in ("rel_features", "local_output", "global_output"))}
+        packed = pack_clips([dict(e) for e in clips], copy=False)
+        assert packed.by_pointer and "features" not in packed and "union_feat" not in packed      # nothing concatenated
+        by_ptr = model(packed)
+        torch.cuda.synchronize()
+        for k, v in ref.items():
+            np.testing.assert_array_equal(by_ptr[k].cpu().numpy(), v, err_msg=k)
+    finally:
+        model.taps = False
+    # the small batch-level tensors a consumer may want appear on first access, identical to the copying pack's
+    for k in ("pair_idx", "im_idx", "labels"):
+        assert torch.equal(by_ptr[k], by_copy[k]), k
+    assert by_ptr["pred_labels"] is by_ptr["labels"]
+    if mode == "sgdet":
+        assert by_ptr["pred_scores"] is by_ptr["scores"] and torch.equal(by_ptr["scores"], by_copy["scores"])
+    for e, many in zip(clips, unpack_predictions(by_ptr)):
+        one = model(dict(e))
+        for k in keys:
+            np.testing.assert_allclose(many[k].cpu().numpy(), one[k].cpu().numpy(), atol=2e-5, rtol=0, err_msg=k)
+
+
+def test_packed_by_pointer_survives_scattered_allocations(predcls):
+    """the clips of a by-pointer batch may live anywhere: interleave their allocations with others, hand them over in
+    an order unrelated to their addresses, and use storage-offset views (a clip cut out of a larger tensor)"""
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    raw = [syn.make_entry(170 + i, c) for i, c in enumerate([[3, 2], [1, 4, 2], [2], [5, 1, 1]])]
+    junk, clips = [], []
+    for i in (2, 0, 3, 1):                                   # allocation order != batch order
+        junk.append(torch.empty(1 << (18 + i), device="cuda"))
+        clips.append((i, _cuda_entry(raw[i])))
+    clips = [e for _, e in sorted(clips, key=lambda t: t[0])]
+    # clip 1 as views into bigger tensors, 3 rows in
+    big = {k: torch.cat([torch.full_like(clips[1][k][:3], 7), clips[1][k]]) for k in ("features", "union_feat", "spatial_masks")}
+    clips[1] = dict(clips[1], **{k: v[3:] for k, v in big.items()})
+    assert all(clips[1][k].storage_offset() > 0 and clips[1][k].is_contiguous() for k in big)
+    ref = unpack_predictions(predcls(pack_clips([dict(e) for e in clips])))
+    got = unpack_predictions(predcls(pack_clips([dict(e) for e in clips], copy=False)))
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        for k in OUT_KEYS:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=k)
+    del junk
+
+
+def test_pointer_table_errors_and_v1_struct(predcls):
+    """C ABI: inconsistent per-clip sizes are refused; a caller compiled against the round-2 header (struct without the
+    tables, STTRAN_INPUTS_V1_SIZE) is still served"""
+    import ctypes as C
+    from nl_vsgg_amd import _native as nat
+    from nl_vsgg_amd.lib.sttran import pack_clips
+    clips = [_cuda_entry(syn.make_entry(180 + i, c)) for i, c in enumerate([[2, 1], [3]])]
+    bad = pack_clips([dict(e) for e in clips], copy=False)
+    bad["clip_num_frames"] = np.array([1, 2], dtype=np.int32)     # clip 0 would own 2 pairs, its tensors hold 3
+    with pytest.raises(nat.SttranError) as ei:
+        predcls(bad)
+    assert ei.value.code == 1
+    # round-2 struct: same call through the contiguous form with the shorter struct_size
+    e = clips[0]
+    ref = {k: predcls(dict(e))[k].clone() for k in OUT_KEYS}
+    lib, h = predcls._lib, predcls._handle
+    P, B = int(e["pair_idx"].shape[0]), int(e["features"].shape[0])
+    counts = np.ascontiguousarray(e["frame_counts"], dtype=np.int32)
+    inp = nat.SttranInputs(struct_size=nat.INPUTS_V1_SIZE, num_clips=1, num_boxes=B, num_pairs=P, num_frames=len(counts),
+                           im_idx_dtype=nat.DTYPE_F32)
+    inp.frame_counts = counts.ctypes.data_as(C.POINTER(C.c_int32))
+    inp.features, inp.pair_idx, inp.labels = e["features"].data_ptr(), e["pair_idx"].data_ptr(), e["labels"].data_ptr()
+    inp.union_feat, inp.spatial_masks, inp.im_idx = e["union_feat"].data_ptr(), e["spatial_masks"].data_ptr(), e["im_idx"].data_ptr()
+    inp.clip_union_feat = C.cast(C.c_void_p(0xdead0000), C.POINTER(C.c_void_p))      # beyond the V1 size: must not be read
+    outs = {k: torch.empty_like(v) for k, v in ref.items()}
+    out = nat.SttranOutputs(struct_size=C.sizeof(nat.SttranOutputs))
+    out.attention_distribution, out.spatial_distribution = outs[OUT_KEYS[0]].data_ptr(), outs[OUT_KEYS[1]].data_ptr()
+    out.contacting_distribution = outs[OUT_KEYS[2]].data_ptr()
+    nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), None))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        assert torch.equal(outs[k], ref[k]), k
+    assert C.sizeof(nat.SttranInputs) > nat.INPUTS_V1_SIZE
+
+
 def test_determinism(predcls):
     e = _cuda_entry(syn.make_entry(77, [3, 5, 2, 4]))
     a = {k: predcls(dict(e))[k].cpu().numpy() for k in OUT_KEYS}
@@ -346,6 +441,12 @@ def test_dsg_detr_packed_clips_equal_single_clips():
     for one, many in zip(singles, unpack_predictions(packed)):
         for k in OUT_KEYS + ("distribution",):
             np.testing.assert_allclose(many[k].cpu().numpy(), one[k], atol=2e-5, rtol=0, err_msg=k)
+    # the same batch by pointer (nothing concatenated; the class sequences come from the clips' own labels / pair_idx
+    # through the chunk table): bit-identical to the copying pack
+    by_ptr = m(pack_clips([_cuda_entry(e) for e in clips], copy=False))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS + ("distribution",):
+        np.testing.assert_array_equal(by_ptr[k].cpu().numpy(), packed[k].cpu().numpy(), err_msg=k)
 
 
 def test_longest_action_genome_clip(predcls, weights):

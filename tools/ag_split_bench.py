@@ -121,7 +121,7 @@ def main():
             for i in range(0, len(chunk), a.pack):
                 group_gt[i] = PackedGroundTruth.concat([gt for _, gt in chunk[i:i + a.pack]])
                 group_gt[i].on(dev)
-        warm = model(pack_clips([dict(c[0]) for c in chunk[:2]]))
+        warm = model(pack_clips([c[0] for c in chunk[:2]], copy=False))
         if a.evaluator == "hip":                # first-use costs of the evaluator (kernel load, pinned-buffer pool): untimed
             w = SceneGraphEvaluator_HIP(**kw); w.register_container(); w.EAGER_BYTES = 0
             w.evaluate_packed([gt for _, gt in chunk[:2]], warm); w.flush()
@@ -132,7 +132,8 @@ def main():
         def loop(e):
             for i in range(0, len(chunk), a.pack):
                 group = chunk[i:i + a.pack]
-                packed_pred = model(pack_clips([dict(c[0]) for c in group]))
+                # by pointer: the clips' tensors are read where they are (no 64-clip concatenation per forward)
+                packed_pred = model(pack_clips([c[0] for c in group], copy=False))
                 if i in group_gt:
                     e.evaluate_packed(group_gt[i], packed_pred)       # the whole pack in one evaluator call
                     continue
