@@ -180,6 +180,80 @@ struct EpiLinearV {
   }
   __device__ __forceinline__ void operator()(int row, int col, float v) const { e(row, col, v); }
 };
+// The same epilogue for a whole strip of NV column groups of ONE output row, in two phases: every load the strip needs
+// (bias, per-slot position bias, residual) is issued first, then the arithmetic and the stores.  Written as NV calls of
+// vec() the compiler must keep the loads of group j + 1 behind the store of group j (C may alias what is loaded), which
+// turns a tile's epilogue into a chain of NV dependent memory round trips per row (~0.5 us each: ~20 us per 128 x 176
+// tile, measured as 4.4 K-steps of 61).  Same operation order as put4 (bit-identical results).
+// cols[j] = first column of group j (col % 4 == 0); no per-column affine here (launchers route those to vec()).
+template <int NV>
+__device__ __forceinline__ void epi_linear_strip(const EpiLinear& e, int row, const int (&cols)[NV], const f32x4 (&acc)[NV]) {
+  // every condition below is wave-uniform (a property of the launch) except the validity of the two output rows, and
+  // loads never sit under a divergent condition: a disabled output row reads row 0 / slot 0 and is masked at the store
+  const bool hb = e.bias != nullptr, hrb = e.rowbias != nullptr, hrs = e.res != nullptr, h2 = e.out_rowidx2 != nullptr;
+  const int o1 = e.out_rowidx ? e.out_rowidx[row] : row;
+  const int o2 = h2 ? e.out_rowidx2[row] : -1;
+  const float* rb1 = hrb ? e.rowbias + (int)e.rowslot[o1 >= 0 ? o1 : 0] * e.rb_ld : nullptr;
+  const float* rb2 = (hrb && h2) ? e.rowbias + (int)e.rowslot[o2 >= 0 ? o2 : 0] * e.rb_ld : nullptr;
+  const float* rs = hrs ? e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[row] : row) * e.ldres : nullptr;
+  const int rbmax = e.rb_cols - 4;                 // columns past rb_cols read (and discard) the last valid group
+  f32x4 b[NV], r1[NV], r2[NV], rr[NV];
+  if (hb) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) b[j] = *reinterpret_cast<const f32x4*>(e.bias + cols[j]);
+  }
+  if (hrb) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) r1[j] = *reinterpret_cast<const f32x4*>(rb1 + min(cols[j], rbmax));
+  }
+  if (hrb && h2) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) r2[j] = *reinterpret_cast<const f32x4*>(rb2 + min(cols[j], rbmax));
+  }
+  if (hrs) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) rr[j] = *reinterpret_cast<const f32x4*>(rs + cols[j]);
+  }
+  f32x4 v0[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v0[j] = acc[j];
+  if (hb) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v0[j] += b[j];
+  }
+  auto finish = [&](int orow, const f32x4 (&rbv)[NV]) {
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = v0[j];
+    if (hrb) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const f32x4 w = v[j] + rbv[j];
+        const bool in = cols[j] < e.rb_cols;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = in ? w[c] : v[j][c];
+      }
+    }
+    if (e.relu) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = relu_nan(v[j][c]);
+    }
+    if (hrs) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] += rr[j];
+    }
+    if (orow >= 0) {
+      float* dst = e.C + (int64_t)orow * e.ldc;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4*>(dst + cols[j]) = v[j];
+    }
+  };
+  finish(o1, r1);
+  if (h2) finish(o2, r2);
+}
+
 // element-wise functors (heads, unaligned outputs) get a vec() that falls back to four scalar calls
 template <class Epi>
 struct EpiScalar4 {

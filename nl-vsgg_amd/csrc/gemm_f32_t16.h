@@ -1,0 +1,334 @@
+// gemm_f32_t16.h -- exact-fp32 MFMA GEMM on 16x16 blocks: the 128 x 176 tile of the N = 1936 family.
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  N % 176 == 0,  both operands on the padded K-major contract (B_KMAJOR_PAD)
+//
+// Why a second tile family (lib/transformer.py:9-12,38-42: nn.MultiheadAttention in/out projections and linear2 all have
+// N = 1936, 3872 or 5808 = 11, 22, 33 x 176):
+//   * 1936 = 16 x 121 has no divisor that is a multiple of 32, so the 32x32x2 tiles of gemm_f32_mfma.h pad it to 2048
+//     (5.8 % of those GEMMs' MFMAs compute columns nobody stores); 176 = 11 blocks of v_mfma_f32_16x16x4_f32 divides it
+//     exactly -- same 64 FLOP/clk/SIMD as the 32x32x2 form;
+//   * the 256 x 128 tile owns a CU alone (111 KB of LDS, 8 waves = 2 per SIMD in ONE workgroup): every wave of the CU is
+//     in the prologue / epilogue of a tile at the same time and the matrix pipe idles meanwhile (~7 % of the kernel, PMC).
+//     Here a workgroup is 4 waves (one per SIMD) on 128 x 176 with 76 KB of LDS, so TWO independent workgroups share a
+//     CU: while one stores its tile and fills its pipeline, the other one's MFMAs keep the pipe busy.
+//
+// Wave w owns rows 32 w .. 32 w + 31 and ALL 176 columns: 2 x 11 accumulators of 4 registers (88 VGPRs).  The weights
+// feed the MFMA's "A" port and the activations its "B" port (as in the swapped-port form of gemm_f32_mfma.h), so a lane
+// holds, per accumulator, four CONSECUTIVE columns of one output row: bias / residual / C are 16-byte accesses.
+// LDS: rows of 32 floats (BK = 32), unpadded, the 16-byte slot index XOR-ed with (row >> 1) & 7 -- ds_read_b128 of a
+// 16-row fragment (lane = (row l % 16, k-chunk l / 16)) is then conflict-free in each of the instruction's four
+// 16-lane groups, and so are the 8-lanes-per-row ds_write_b128 of the staging.  One ds_read_b128 feeds four MFMAs
+// (element e of both fragments = k 16 kb + 4 (l / 16) + e: the same permutation of k for both operands).
+// Global -> VGPR -> LDS staging one K-step ahead: the loads of step t + 1 are issued behind the first MFMAs of step t and
+// written to the other stage behind its last ones (~0.8 K-step = 4 us in flight; the co-resident workgroup covers the rest).
+// Schedule: the hybrid data-parallel + stream-K plan of gemm_f32_mfma.h (same SkRange / parking / fix-up scheme).
+#pragma once
+#include <type_traits>
+
+#include "gemm_f32_mfma.h"
+
+namespace sttran {
+
+#ifdef STTRAN_GEMM_EXPERIMENT
+// phase clocks of the 128 x 176 kernel (experiment builds, STTRAN_T16_ABLATE=9): summed over workgroups, s_memtime ticks
+// [0] prologue (tile start -> first MFMA), [1] main loop, [2] epilogue / parking, [3] tiles, [4] K-steps
+__device__ unsigned long long g_t16_clk[8];
+#endif
+
+template <int BM_, int BN_>
+struct Tile16 {
+  static constexpr int BM = BM_, BN = BN_;
+  static constexpr int WAVES = BM / 32, NT = WAVES * 64;
+  static constexpr int NB = BN / 16;                       // 16-column blocks per wave (all of the tile's columns)
+  static constexpr int ROWS = BM + BN;                     // staged rows per K-step
+  static constexpr int STAGE = ROWS * kBK;                 // floats per LDS stage (unpadded 128-byte rows)
+  static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static constexpr int AV = BM * 8 / NT;                   // 16-byte pieces per thread per K-step, A rows
+  static constexpr int BVF = (BN * 8) / NT;                // ... B rows: full rounds
+  static constexpr int BREM = BN * 8 - BVF * NT;           // ... and the threads of the last, partial round
+  static constexpr int BV = BVF + (BREM ? 1 : 0);
+  static constexpr int GROUP_N = 8;
+  static constexpr int RPR = NT / 8;                       // rows staged per round (8 threads per 128-byte row)
+  static_assert(BM % 32 == 0 && BN % 16 == 0 && BM % RPR == 0 && BREM % 64 == 0 && RPR % 16 == 0, "tile shape");
+};
+
+// ABL: timing-only ablations for tools/gemm_bench.py (wrong results): 1 = no global loads in the loop, 2 = no global
+// loads and no ds_writes, 3 = no barrier, 4 = all of them (LDS reads + MFMAs only), 5 = loads but no ds_writes
+template <class T, class Epi, int ABL = 0>
+__global__ void __launch_bounds__(T::NT, 2)
+gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
+              int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB, AV = T::AV, BV = T::BV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  // fragment read offsets (floats) of this lane inside a 16-row block: row fr, slot (4 kb + fg) ^ ((fr >> 1) & 7)
+  const int swz = (fr >> 1) & 7;
+  const int frag0 = fr * kBK + ((fg ^ swz) << 2);          // kb = 0;  kb = 1 is frag0 ^ 16 (slot ^ 4)
+  const int a_base = wave * 32 * kBK;                      // this wave's first A row
+  // staging: thread = (row tid >> 3 of a 32-row round, 16-byte chunk tid & 7); LDS slot swizzled by the row
+  const int srow = tid >> 3, schunk = tid & 7;
+  const int st_off = srow * kBK + ((schunk ^ ((srow >> 1) & 7)) << 2);   // + round * RPR rows (RPR % 16 == 0: same swizzle)
+  // B rows: BN = 176 is 5.5 rounds of 32 rows.  The last round has no branch: its upper half of the threads stages the
+  // SAME rows as the lower half (row - 16: identical data to identical LDS addresses), so every thread runs the same
+  // unconditional loads and stores
+  constexpr int RPR = T::RPR;
+  auto brow = [&](int i) { const int r = srow + RPR * i; return r < BN ? r : r - 16; };
+  static_assert(T::BREM == 0 || BN - T::BVF * RPR >= 16, "partial B round: its idle rows re-stage the 16 rows in front of them");
+  static_assert(T::BREM == 0 || T::BV * RPR - BN <= 16, "partial B round: at most 16 idle rows");
+  const int st_last = st_off + (BV - 1) * RPR * kBK - (srow + RPR * (BV - 1) < BN ? 0 : 16 * kBK);
+
+  const int G = gridDim.x;
+  const int blk = xcd_remap(blockIdx.x, G);
+  const int tiles_dp = dp_per_wg * G;
+  const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
+  // PHASE DIVERSITY.  Every workgroup runs the same number of equally long tiles, so left alone all of them reach the end
+  // of a tile at the same moment and 512 workgroups store (and read residuals for) 45 MB of C at once: the burst takes
+  // ~12 us to drain, the operand loads of every next tile queue behind it, and neither resident of a CU has MFMAs to
+  // issue (measured with s_memtime: 13-15 us from the last MFMA of a tile to its last store; 4.4 K-steps of a 61-step
+  // tile).  The stream-K range of a workgroup is therefore cut at the tile border it crosses: the part in front of the
+  // border runs BEFORE the whole tiles, the rest after them (a range that crosses no border goes first or last by
+  // parity).  The lengths of the leading parts are spread evenly over 0 .. range length, so the tile ends of the chip are
+  // spread over time instead of coinciding; which workgroup computes what -- and the parked partials -- are unchanged.
+  int pre_end = rg.begin;
+  if (half < (int)gridDim.x && rg.end > rg.begin) {
+    const int border = (rg.begin / ksteps + 1) * ksteps;            // first tile border behind the start of the range
+    pre_end = border < rg.end ? border : ((blk & 1) ? rg.end : rg.begin);
+  }
+
+  int dp_done = 0;
+  for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
+    int tile, ks0, ks1;
+    const bool dp = dp_done < dp_per_wg && !(it < pre_end);
+    if (dp) {
+      tile = dp_done * G + blk;
+      ks0 = 0; ks1 = ksteps;
+      ++dp_done;
+    } else {
+      const int t = it / ksteps;
+      tile = tiles_dp + t;
+      ks0 = it - t * ksteps;
+      ks1 = min(ksteps, ks0 + (rg.end - it));
+    }
+    const int nsteps = ks1 - ks0;
+    int tile_m, tile_n;
+    tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#ifdef STTRAN_GEMM_EXPERIMENT
+    unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
+    if constexpr (ABL == 9) clk0 = __builtin_readcyclecounter();
+#endif
+
+    // global source of every staged piece, as a 32-bit BYTE offset from the operand's base (the launcher guarantees the
+    // operands span less than 4 GB; a uniform base + 32-bit lane offset is one VGPR per piece instead of two).  Rows past M
+    // read row 0 of the operand: never stored by the epilogue.
+    uint32_t oa[AV], ob[BV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int g = m0 + srow + RPR * i;
+      const int64_t prow = g < M ? (A.rowidx ? A.rowidx[g] : g) : 0;
+      oa[i] = (uint32_t)((prow * A.ld + schunk * 4 + ks0 * kBK) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) ob[i] = (uint32_t)(((int64_t)(n0 + brow(i)) * B.ld + schunk * 4 + ks0 * kBK) * 4);
+    const char* const abase = reinterpret_cast<const char*>(A.ptr);
+    const char* const bbase = reinterpret_cast<const char*>(B.ptr);
+    // two register sets: the global loads of K-step u go to set u & 1, TWO steps ahead of their use (issued during step
+    // u - 2, written to LDS during step u - 1), so a load has more than a whole K-step (~5 us) to arrive from HBM
+    f32x4 ra[2][AV], rb[2][BV];
+    auto koff = [&](int step) { return (step < nsteps ? step : 0) * kBK; };   // steps past the end re-read step 0 (never used)
+    auto load_piece = [&](int set, int n, int ko) {
+      if (n < AV) ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)ko * 4u));
+      else rb[set][n - AV] = *reinterpret_cast<const f32x4*>(bbase + (ob[n - AV] + (uint32_t)ko * 4u));
+    };
+    auto store_piece = [&](int set, int n, float* stage) {
+      if (n < AV) *reinterpret_cast<f32x4*>(stage + st_off + n * RPR * kBK) = ra[set][n];
+      else *reinterpret_cast<f32x4*>(stage + BM * kBK + (n - AV == BV - 1 ? st_last : st_off + (n - AV) * RPR * kBK)) = rb[set][n - AV];
+    };
+
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NBLK = 2 * NB, NPL = AV + BV;
+    static_assert(NPL <= NB - 1, "staging pieces must fit the blocks of half a K-step");
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) load_piece(0, n, koff(0));
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) load_piece(1, n, koff(1));
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) store_piece(0, n, smem);
+    __syncthreads();
+
+    // ---- software-pipelined main loop ------------------------------------------------------------------------------
+    // A K-step is NBLK = 2 NB "blocks" (k16 group kb, column block j) of 8 MFMAs (2 row blocks x 4 k); block s uses the
+    // B fragment fb[s & 1] and the A fragments fa[kb].  While block s runs, the fragment of block s + 1 is read from LDS
+    // into the other register set (and the kb = 1 A fragments a few blocks ahead), one global load (of the K-step after
+    // the next) rides in each of the first blocks and one ds_write (of the next K-step) in each of the last ones.  The
+    // LAST block of a step is held in registers across the barrier: its MFMAs run after the first fragment reads of the
+    // next step have been issued and cover the barrier wait and their latency (as the 32x32x2 kernel does with its last
+    // group).  sched_group_barrier pins "MFMA, one memory instruction, MFMA ..." inside a block: left alone the compiler
+    // issues every LDS read right in front of its first use and waits for it (a ~100-cycle stall every 8 MFMAs).
+    f32x4 fa[2][2], fb[2];
+    auto read_a = [&](const float* stage, int kb) {
+      const int fo = kb ? (frag0 ^ 16) : frag0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[kb][i] = *reinterpret_cast<const f32x4*>(stage + a_base + i * 16 * kBK + fo);
+    };
+    auto read_b = [&](const float* stage, int sblk) {
+      const int kb = sblk / NB, j = sblk - kb * NB;
+      fb[sblk & 1] = *reinterpret_cast<const f32x4*>(stage + (BM + j * 16) * kBK + (kb ? (frag0 ^ 16) : frag0));
+    };
+    auto mma_block = [&](int sblk) {
+      const int kb = sblk / NB, j = sblk - kb * NB;
+      // (e outer, i inner: two independent accumulators alternate, so an MFMA never waits for the 40-cycle
+      //  dependent-accumulator latency of the one issued 32 cycles before it)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[sblk & 1][e], fa[kb][i][e], acc[i][j], 0, 0, 0);
+    };
+    read_a(smem, 0);
+    read_b(smem, 0);
+#ifdef STTRAN_GEMM_EXPERIMENT
+    if constexpr (ABL == 9) clk1 = __builtin_readcyclecounter();
+#endif
+    // one K-step; `set` (compile-time) = t & 1: receives the loads of step t + 2, the other set (step t + 1) goes to LDS
+    auto k_step = [&](int t, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const float* cur = smem + set * T::STAGE;
+      float* nxt = smem + (set ^ 1) * T::STAGE;
+      const int ko = koff(t + 2);
+#pragma unroll
+      for (int sb = 0; sb < NBLK; ++sb) {
+        constexpr bool kLoads = ABL != 1 && ABL != 2 && ABL != 4, kStores = ABL != 2 && ABL != 4 && ABL != 5;
+        if (sb + 1 < NBLK) read_b(cur, sb + 1);
+        if (sb == NB - 3) read_a(cur, 1);                   // the kb = 1 row fragments, two blocks before their first use
+        if (sb < NPL && kLoads) load_piece(set, sb, ko);
+        if (sb >= NBLK - NPL && kStores) store_piece(set ^ 1, sb - (NBLK - NPL), nxt);
+        if (sb + 1 < NBLK) {
+          mma_block(sb);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb < NPL && kLoads) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (sb >= NBLK - NPL && kStores) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ABL != 3 && ABL != 4) __syncthreads();
+      read_a(nxt, 0);
+      read_b(nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);                    // issue these reads BEFORE the held-over block, which then hides them
+      mma_block(NBLK - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      int t = 0;
+      for (; t + 1 < nsteps; t += 2) {
+        k_step(t, std::integral_constant<int, 0>{});
+        k_step(t + 1, std::integral_constant<int, 1>{});
+      }
+      if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
+    }
+    if constexpr (ABL == 5) {          // loads issued but never written to LDS: keep them alive, wait for them only here
+#pragma unroll
+      for (int n = 0; n < AV; ++n) asm volatile("" ::"v"(ra[0][n]), "v"(ra[1][n]));
+#pragma unroll
+      for (int n = 0; n < BV; ++n) asm volatile("" ::"v"(rb[0][n]), "v"(rb[1][n]));
+    }
+
+#ifdef STTRAN_GEMM_EXPERIMENT
+    if constexpr (ABL == 9) clk2 = __builtin_readcyclecounter();
+#endif
+    // C layout (weights on the "A" port): output row = lane % 16 of block i, columns 4 (lane / 16) + {0..3} of block j
+    const int row0 = m0 + wave * 32 + fr;
+    const int col0 = n0 + 4 * fg;
+    if (nsteps == ksteps) {
+      // a row's strip in two halves (register budget): all loads of a half are issued before its stores
+      constexpr int H0 = (NB + 1) / 2, H1 = NB - H0;
+      int c0[H0], c1[H1 > 0 ? H1 : 1];
+#pragma unroll
+      for (int j = 0; j < H0; ++j) c0[j] = col0 + 16 * j;
+#pragma unroll
+      for (int j = 0; j < H1; ++j) c1[j] = col0 + 16 * (H0 + j);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = row0 + 16 * i;
+        if (r < M) {
+          f32x4 a0[H0], a1[H1 > 0 ? H1 : 1];
+#pragma unroll
+          for (int j = 0; j < H0; ++j) a0[j] = acc[i][j];
+#pragma unroll
+          for (int j = 0; j < H1; ++j) a1[j] = acc[i][H0 + j];
+          epi_linear_strip<H0>(epi.e, r, c0, a0);
+          if constexpr (H1 > 0) epi_linear_strip<H1>(epi.e, r, c1, a1);
+        }
+      }
+    } else {
+      // partial K range: park the raw accumulators, register-major (1 KB per wave-instruction); gemm16_fixup_kernel sums
+      // them in ascending workgroup order (deterministic) and runs the epilogue
+      f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sp[(i * NB + j) * NT] = acc[i][j];
+    }
+#ifdef STTRAN_GEMM_EXPERIMENT
+    if constexpr (ABL == 9) {
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long clk3 = __builtin_readcyclecounter();
+      if (tid == 0) {
+        atomicAdd(&g_t16_clk[0], clk1 - clk0); atomicAdd(&g_t16_clk[1], clk2 - clk1); atomicAdd(&g_t16_clk[2], clk3 - clk2);
+        atomicAdd(&g_t16_clk[3], 1ull); atomicAdd(&g_t16_clk[4], (unsigned long long)nsteps);
+      }
+    }
+#endif
+    if (!dp) it += nsteps;
+  }
+}
+
+// grid = (stream-K tiles, 2 * NB): one workgroup per accumulator register group of a split tile
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT)
+gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
+                    const float* __restrict__ slab, Epi epi) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB;
+  const int tile = blockIdx.x;
+  const int t0 = tile * ksteps, t1 = t0 + ksteps;
+  const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t1 - 1, sk_base, sk_rem);
+  if (b_lo == b_hi) return;                      // computed whole by one workgroup: nothing parked
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int ij = blockIdx.y, i = ij / NB, j = ij % NB;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* base = reinterpret_cast<const f32x4*>(slab) + (int64_t)ij * NT + tid;
+  for (int b = b_lo; b <= b_hi; b += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = b + u;
+      const bool ok = bb <= b_hi;
+      const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
+      const f32x4* sp = base + ((int64_t)(ok ? bb : b_lo) * 2 + slot) * (BM * BN / 4);
+      v[u] = ok ? *sp : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  const int gt = tiles_dp + tile;
+  int tile_m, tile_n;
+  tile_origin<T::GROUP_N>(gt, tiles_m, tiles_n, tile_m, tile_n);
+  const int row = tile_m * BM + wave * 32 + 16 * i + fr;
+  const int col = tile_n * BN + 16 * j + 4 * fg;
+  if (row < M) epi.vec(row, col, acc);
+}
+
+}  // namespace sttran

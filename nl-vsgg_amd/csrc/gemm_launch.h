@@ -14,13 +14,18 @@ struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 // (tools/gemm_bench.py --shapes big on MI355X); blocks_per_cu = persistent workgroups per CU
 // (bounded by LDS: 111 / 74 / 37 / 55 KB per workgroup).
 static const TileInfo kTiles[TILE_COUNT] = {
-    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2}};
+    {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
+    {128, 176, 0.93f, 2},    // gemm_f32_t16.h: 76 KB of LDS, two workgroups of 4 waves per CU
+    {256, 176, 0.93f, 1}};   // ... 108 KB of LDS, one workgroup of 8 waves
 
 // Hybrid data-parallel + stream-K schedule of one GEMM: G persistent workgroups each run dp_per_wg whole
 // tiles; the tiles_sk leftover tiles (< G) are cut into g_sk equal iteration ranges.
 struct SkPlan { int G, dp_per_wg, tiles_sk, g_sk; };
 static SkPlan sk_plan(int tile, int64_t tiles, int64_t ksteps) {
-  const int64_t g = (int64_t)num_cus() * kTiles[tile].blocks_per_cu;
+  int64_t g = (int64_t)num_cus() * kTiles[tile].blocks_per_cu;
+#ifdef STTRAN_GEMM_EXPERIMENT
+  if (tile == TILE_128x176 && getenv("STTRAN_T16_BPC")) g = (int64_t)num_cus() * atoi(getenv("STTRAN_T16_BPC"));
+#endif
   SkPlan p;
   // never cut finer than kMinSteps K-steps per workgroup: below that the per-segment prologue dominates
   static const int kMinSteps = getenv("STTRAN_SK_MIN_STEPS") ? std::max(1, atoi(getenv("STTRAN_SK_MIN_STEPS"))) : 4;
@@ -108,5 +113,8 @@ hipError_t gemm_linear_s4(hipStream_t s, const GemmOperand& A, const GemmOperand
                           const EpiLinear& epi, GemmPlan plan, float* slab);       // padded operands, scalar epilogue
 hipError_t gemm_linear_sel(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                            const EpiLinear& epi, GemmPlan plan, float* slab);      // arbitrary operands (zero-select)
+// the 128 x 176 tile on 16x16x4 MFMA blocks (kernels_gemm_t16.hip): N % 176 == 0, padded operands, 16-byte epilogue
+hipError_t gemm_linear_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                           const EpiLinear& epi, float* slab, int tile);
 
 }  // namespace sttran

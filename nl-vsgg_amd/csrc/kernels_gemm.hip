@@ -22,6 +22,10 @@ int num_cus() {
   return n;
 }
 
+// below this many rows the planner keeps the 32x32x2 tiles (small-M launches are latency-bound: measured in
+// tools/gemm_bench.py --shapes path16 / path16x8)
+static const int64_t kT16MinRows = getenv("STTRAN_T16_MIN_ROWS") ? atoll(getenv("STTRAN_T16_MIN_ROWS")) : 1024;
+
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split) {
   (void)force_split;   // split-K is subsumed by the stream-K schedule
   GemmPlan best{TILE_128x128, 1};
@@ -32,6 +36,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   if (force_tile < 0 || force_tile >= TILE_COUNT) force_tile = 0;
   for (int t = 1; t < TILE_COUNT; ++t) {
     if (force_tile && t != force_tile) continue;
+    // the 176-column tile only serves N = 11 k x 16 exactly (1936 / 3872 / 5808); gemm_linear falls back to 256 x 128
+    // when the operands / epilogue do not meet its contract
+    if ((t == TILE_128x176 || t == TILE_256x176) && (N % 176 != 0 || (!force_tile && M < kT16MinRows))) continue;
+    if (t == TILE_256x176 && !force_tile) continue;     // measured equal or slower than 128 x 176 at every shape of the path: by request only
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -82,6 +90,12 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
   if (M <= 0 || N <= 0) return hipSuccess;
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
+  if (plan.tile == TILE_128x176 || plan.tile == TILE_256x176) {
+    if (padded && N % 176 == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff && aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) &&
+        (B.ld & 3) == 0)
+      return gemm_linear_t16(s, A, B, M, N, K, epi, slab, plan.tile);
+    plan.tile = TILE_256x128;                          // contract not met: the general engine
+  }
   if (!padded) return gemm_linear_sel(s, A, B, M, N, K, epi, plan, slab);
   if (epi_vectorizable(epi, N)) return gemm_linear_vec(s, A, B, M, N, K, epi, plan, slab);
   return gemm_linear_s4(s, A, B, M, N, K, epi, plan, slab);

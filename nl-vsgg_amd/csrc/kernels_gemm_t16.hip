@@ -1,0 +1,84 @@
+// kernels_gemm_t16.hip -- the 128 x 176 tile of the N = 1936 family (gemm_f32_t16.h): instantiation and launch
+#include <cstdio>
+
+#include "gemm_f32_t16.h"
+#include "gemm_launch.h"
+
+namespace sttran {
+
+template <class T, int TILE_ID>
+static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                             const EpiLinear& epi, float* slab) {
+  using Epi = EpiLinearV;
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (N % T::BN != 0) return hipErrorInvalidValue;
+  static DeviceMarks marks;
+  auto kern = gemm16_kernel<T, Epi>;
+#ifdef STTRAN_GEMM_EXPERIMENT
+  {
+    static DeviceMarks m1, m2, m3, m4, m5, m9;
+    const char* v = getenv("STTRAN_T16_ABLATE");
+    const int abl = v ? atoi(v) : 0;
+    if (abl == 1) { kern = gemm16_kernel<T, Epi, 1>; if (m1.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+    if (abl == 2) { kern = gemm16_kernel<T, Epi, 2>; if (m2.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+    if (abl == 3) { kern = gemm16_kernel<T, Epi, 3>; if (m3.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+    if (abl == 5) { kern = gemm16_kernel<T, Epi, 5>; if (m5.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+    if (abl == 9) { kern = gemm16_kernel<T, Epi, 9>; if (m9.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+    if (abl == 4) { kern = gemm16_kernel<T, Epi, 4>; if (m4.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown; }
+  }
+#endif
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(gemm16_kernel<T, Epi>), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+#ifdef STTRAN_GEMM_EXPERIMENT
+  {
+    static bool once = false;
+    if (!once && getenv("STTRAN_T16_OCC")) {
+      once = true;
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm16_kernel<T, Epi>, T::NT, T::LDS_BYTES);
+      hipFuncAttributes fa{};
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm16_kernel<T, Epi>));
+      fprintf(stderr, "t16 occupancy: %d blocks/CU (err %d), lds dyn %d static %zu, regs %d, maxDyn %d\n", nb, (int)e, T::LDS_BYTES,
+              fa.sharedSizeBytes, fa.numRegs, fa.maxDynamicSharedSizeBytes);
+    }
+  }
+#endif
+  const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles = tm * tn;
+  const int ksteps = (K + kBK - 1) / kBK;
+  const SkPlan sp = sk_plan(TILE_ID, tiles, ksteps);
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
+  bool split = false;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
+  const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
+  const Epi e{epi};
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
+                     base, rem, half, slab, e);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess || !split) return err;
+  hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps,
+                     sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, e);
+  return hipGetLastError();
+}
+
+hipError_t gemm_linear_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
+                           const EpiLinear& epi, float* slab, int tile) {
+  if (tile == TILE_256x176) return launch_t16<Tile16<256, 176>, TILE_256x176>(s, A, B, M, N, K, epi, slab);
+  return launch_t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, epi, slab);
+}
+
+#ifdef STTRAN_GEMM_EXPERIMENT
+// reads and clears the phase clocks (tools/gemm_bench.py --phases)
+extern "C" int sttran_debug_t16_clocks(unsigned long long* out8) {
+  unsigned long long z[8] = {};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_t16_clk), sizeof(z)) != hipSuccess) return 2;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_t16_clk), z, sizeof(z)) == hipSuccess ? 0 : 2;
+}
+#endif
+
+}  // namespace sttran

@@ -85,7 +85,34 @@ def test_gemm_padded_path(lib, M, N, K, tile):
     assert (Cc.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(2816, 1936, 1936), (5280, 1936, 2048), (330, 5808, 1936), (700, 3872, 1936), (1, 176, 32),
+                                   (129, 352, 100), (21120, 1936, 1936)])
+@pytest.mark.parametrize("tile", [5, 6])
+def test_gemm_tile_128x176(lib, M, N, K, tile):
+    """the 16x16x4-MFMA tile of the N = 1936 family (gemm_f32_t16.h): exact in N, two workgroups per CU, XOR-swizzled LDS;
+    bias + ReLU + residual through the 16-byte epilogue, stream-K remainders through its own fix-up kernel"""
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 5 * K)
+    Kp = (K + 31) // 32 * 32
+    A = torch.randn(M + 1, Kp, device="cuda", generator=g) * 3          # pad columns: garbage (W is zero there)
+    W = torch.zeros(N, Kp, device="cuda")
+    W[:, :K] = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(W), Kp, _p(b), _p(res), _p(Cc), M, N, K, 1, tile, None) == 0
+    torch.cuda.synchronize()
+    ref = _ref(A[:M, :K], W[:, :K], b, res, relu=1)
+    tol = 1e-5 * (K ** 0.5) * 12 + 1e-5
+    assert torch.isfinite(Cc).all()
+    assert (Cc.double() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item() / (K ** 0.5))
+    # deterministic: the parked stream-K partials are summed in a fixed order
+    C2 = torch.empty_like(Cc)
+    assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(W), Kp, _p(b), _p(res), _p(C2), M, N, K, 1, tile, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(Cc, C2)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 def test_gemm_padded_path_gathered_rows(lib, tile):
     """A rows gathered through an index (subj/obj FC, last-decoder-layer row pruning), every tile"""
     g = torch.Generator(device="cuda").manual_seed(40 + tile)

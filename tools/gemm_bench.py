@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nl_vsgg_amd import _native  # noqa: E402
 
-TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64", 6: "D128x128", 7: "D256x128", 8: "D128x64", 9: "D64x64"}
+TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64", 5: "128x176", 6: "256x176"}
 
 
 def path_shapes(P, NT):
@@ -36,6 +36,7 @@ SHAPES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="big")
+    ap.add_argument("--one", default="", help="M,N,K: a single shape instead of a --shapes set")
     ap.add_argument("--tiles", default="1,2,3,4")
     ap.add_argument("--pipes", default="0", help="main-loop variants (library built with EXTRA=-DSTTRAN_GEMM_EXPERIMENT)")
     ap.add_argument("--iters", type=int, default=10)
@@ -54,7 +55,8 @@ def main():
         lib.sttran_debug_mfma_peak(20000, C.byref(pk))
     print(f"device fp32-MFMA rate (register-only loop): {pk.value:.1f} TFLOP/s (spec peak 157.3)")
     flush = torch.zeros(192 * 1024 * 1024, device="cuda") if a.cold else None
-    for name, M, N, K in SHAPES[a.shapes]:
+    shapes = [("one",) + tuple(int(v) for v in a.one.split(","))] if a.one else SHAPES[a.shapes]
+    for name, M, N, K in shapes:
         Kp = (K + 31) // 32 * 32                     # the product's layout: rows padded to 32 columns, W zero there
         A = torch.randn(M + 1, Kp, device="cuda")
         W = torch.zeros(N, Kp, device="cuda")
@@ -67,9 +69,17 @@ def main():
         pr = p(R) if a.residual else None
         best = None
         rows = []
+        # clocks ramp over the first tens of milliseconds of load after an idle gap (the allocations above): without this
+        # the FIRST configuration measured for a shape reads 2-8 % low
+        t_end = torch.cuda.Event(enable_timing=True); t_beg = torch.cuda.Event(enable_timing=True)
+        t_beg.record()
+        for _ in range(max(4, int(6e10 / max(1.0, 2.0 * M * N * K)))):       # ~60 ms of work
+            lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, 1, None)
+        t_end.record(); torch.cuda.synchronize()
         for tile in [0] + [int(t) for t in a.tiles.split(",")]:
             for split in ([0] if tile == 0 else [int(s) for s in a.pipes.split(",")]):
                 os.environ["STTRAN_GEMM_PIPE"] = str(split)     # only read by EXPERIMENT builds
+                os.environ["STTRAN_T16_ABLATE"] = str(split)    # ... the 128x176 tile's ablations (same --pipes list)
                 for _ in range(2):
                     lib.sttran_debug_gemm_padded(p(A), Kp, None, p(W), Kp, p(b), pr, p(Cc), M, N, K, 0, tile, None)
                 torch.cuda.synchronize()
