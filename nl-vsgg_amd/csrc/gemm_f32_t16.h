@@ -153,7 +153,7 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int NBLK = 2 * NB, NPL = AV + BV;
-    static_assert(NPL <= NB - 1, "staging pieces must fit the blocks of half a K-step");
+    static_assert(NPL <= NB, "staging pieces must fit the blocks of half a K-step");
 #pragma unroll
     for (int n = 0; n < NPL; ++n) load_piece(0, n, koff(0));
 #pragma unroll

@@ -34,7 +34,7 @@ int num_cus();   // compute units of the current device (cached per ordinal)
 // tiles of gemm_f32_mfma.h (ids are part of the sttran_debug_gemm test hook: keep them stable)
 // 5: gemm_f32_t16.h (16x16x4 MFMA blocks; N % 176 == 0, padded operands, vector epilogue only)
 enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_128x176 = 5, TILE_256x176 = 6,
-       TILE_COUNT = 7 };
+       TILE_T128x128 = 7, TILE_COUNT = 8 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);
 size_t gemm_slab_floats(const GemmPlan& p, int64_t M, int64_t N);

@@ -39,6 +39,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
     // the 176-column tile only serves N = 11 k x 16 exactly (1936 / 3872 / 5808); gemm_linear falls back to 256 x 128
     // when the operands / epilogue do not meet its contract
     if ((t == TILE_128x176 || t == TILE_256x176) && (N % 176 != 0 || (!force_tile && M < kT16MinRows))) continue;
+    if (t == TILE_T128x128 && (N % 128 != 0 || (!force_tile && M < kT16MinRows))) continue;
     if (t == TILE_256x176 && !force_tile) continue;     // measured equal or slower than 128 x 176 at every shape of the path: by request only
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
@@ -90,8 +91,8 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
   if (M <= 0 || N <= 0) return hipSuccess;
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
-  if (plan.tile == TILE_128x176 || plan.tile == TILE_256x176) {
-    if (padded && N % 176 == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff && aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) &&
+  if (plan.tile == TILE_128x176 || plan.tile == TILE_256x176 || plan.tile == TILE_T128x128) {
+    if (padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff && aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) &&
         (B.ld & 3) == 0)
       return gemm_linear_t16(s, A, B, M, N, K, epi, slab, plan.tile);
     plan.tile = TILE_256x128;                          // contract not met: the general engine

@@ -223,6 +223,7 @@ const char* tile_name(int tile) {
     case TILE_64x64: return "64,64,2,2";
     case TILE_128x176: return "128,176,4,1";
     case TILE_256x176: return "256,176,8,1";
+    case TILE_T128x128: return "128,128,4,1";
     default: return "?";
   }
 }
