@@ -43,13 +43,43 @@ def test_version_and_null_handle(native):
 def test_struct_sizes(native):
     # the library rejects any struct whose struct_size differs from its own sizeof
     assert C.sizeof(native.SttranConfig) == 14 * 4
-    assert C.sizeof(native.SttranInputs) == 8 + 16 + 8 + 16 + 8 * 8
+    assert native.INPUTS_V1_SIZE == 8 + 16 + 8 + 16 + 8 * 8                 # round-2 callers' struct (no pointer tables)
+    assert C.sizeof(native.SttranInputs) == native.INPUTS_V1_SIZE + 9 * 8    # + 7 pointer tables + 2 size arrays
+    assert native.SttranInputs.clip_features.offset == native.INPUTS_V1_SIZE
     assert C.sizeof(native.SttranOutputs) == 8 + 7 * 8
     assert C.sizeof(native.SttranProfile) == 8 + 4 * 8 * 8
     lib = native.load()
     cfg = native.SttranConfig(struct_size=4)
     h = C.c_void_p()
     assert lib.sttran_create(C.byref(cfg), C.byref(h)) == 1      # STTRAN_ERR_INVALID, no GPU touched
+
+
+def test_ctypes_structs_match_the_c_header(native, tmp_path):
+    """what a C compiler makes of include/sttran_hip.h (plain C11: the header must not need C++) vs the ctypes mirror"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "sizes.c"
+    src.write_text("""
+#include <stddef.h>
+#include <stdio.h>
+#include "sttran_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %u %zu %zu\\n", sizeof(SttranConfig), sizeof(SttranInputs), sizeof(SttranOutputs),
+         sizeof(SttranProfile), sizeof(SttranProfEntry), sizeof(SttranEvalInputs), sizeof(SttranObjclsSelect),
+         STTRAN_INPUTS_V1_SIZE, offsetof(SttranInputs, clip_features), offsetof(SttranInputs, clip_num_pairs));
+  return 0;
+}
+""")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [C.sizeof(native.SttranConfig), C.sizeof(native.SttranInputs), C.sizeof(native.SttranOutputs),
+            C.sizeof(native.SttranProfile), C.sizeof(native.SttranProfEntry), C.sizeof(native.SttranEvalInputs),
+            C.sizeof(native.SttranObjclsSelect), native.INPUTS_V1_SIZE, native.SttranInputs.clip_features.offset,
+            native.SttranInputs.clip_num_pairs.offset]
+    assert got == want
 
 
 def test_eval_recall_argument_checks(native):
