@@ -32,7 +32,10 @@ enum {
                               (tools/test_STTran.py:83-87); here it is an explicit error  */
   STTRAN_ERR_WEIGHTS = 4,  /* forward before all tensors of the state-dict were loaded    */
   STTRAN_ERR_ORDER = 5,    /* im_idx not sorted ascending (lib/transformer.py:138 assumes) */
-  STTRAN_ERR_LIMIT = 6     /* a sequence exceeds the attention kernel's key limit          */
+  STTRAN_ERR_LIMIT = 6,    /* more pairs than 32-bit indexing allows, or (DSG-DETR) a class
+                              sequence over more frames than the positional table has rows */
+  STTRAN_ERR_INDEX = 7     /* sttran_sync_check: a kernel met a pair_idx / labels entry out of range (torch raises an
+                              IndexError at lib/sttran.py:381-393; the kernels clamp the value and flag it) */
 };
 
 enum { STTRAN_MODE_PREDCLS = 0, STTRAN_MODE_SGCLS = 1, STTRAN_MODE_SGDET = 2 };
@@ -197,7 +200,7 @@ int sttran_union_boxes_masks(const float* boxes, const int64_t* pair_idx, const 
  * gt_rels rows are (subject box, object box, predicate id) with box ids local to the frame.
  * flags [num_gt_rels, 9] uint8: flags[g][3*m + k] = 1 when relation g is hit within the first
  * {10, 20, 50}[k] predictions of metric m (0 with constraint, 1 no constraint, 2 semi constraint).
- * status (int32, device, caller zeroes it): bit 0 = a frame has more pairs than sttran_eval_max_pairs(),
+ * status (int32, device, caller zeroes it): bit 0 = unused since round 3 (a frame of any size is scored: sttran_eval_max_pairs),
  * bit 1 = pair_idx out of range; frames that set a bit get all-zero flags. */
 typedef struct SttranEvalInputs {
   int32_t struct_size;
@@ -224,7 +227,8 @@ typedef struct SttranEvalInputs {
   const int32_t* gt_rels;        /* [num_gt_rels, 3]                                               */
 } SttranEvalInputs;
 int sttran_eval_recall(const SttranEvalInputs* in, uint8_t* flags, int32_t* status, void* stream);
-/* most pairs one frame may have for the given number of predicate columns (26 -> 96) */
+/* pairs of one frame that fit ONE pass of the kernel's key buffer for the given number of predicate columns (26 -> 96);
+ * larger frames are scored in several passes whose top-50 lists are merged: not a limit, a performance knee */
 int32_t sttran_eval_max_pairs(int32_t num_predicates);
 
 /* SGDet WITHOUT weak supervision: the `else` branch of `ObjectClassifier.forward`, lib/sttran.py:185-283,
@@ -237,8 +241,10 @@ int32_t sttran_eval_max_pairs(int32_t num_predicates);
  * 1.. (:243-244); `human_idx` = per frame the row with the largest column-0 score, 0 for a frame without boxes, whose
  * label becomes 1 and whose score becomes that column-0 value (:247-254, the empty-frame assignment to row 0 included);
  * pairs (human of the frame, every other-labelled box of the frame) in frame order (:256-268).
- * Inputs are device pointers; `boxes` [B,5] must be sorted by frame id (column 0).  Every output array must hold
- * `capacity` >= 8 * num_boxes rows (each clean_class pass can at most double a frame's boxes; NMS only removes).
+ * Inputs are device pointers; `boxes` [B,5] must be sorted by frame id (column 0) with every id in [0, num_frames):
+ * STTRAN_ERR_ORDER otherwise (the reference selects rows by `boxes[:,0] == i` and takes any order; sort first).  Every
+ * output array must hold `capacity` >= 4 * num_boxes rows (a box has at most one copy per clean_class pass, and only the
+ * newest copy of a chain can be copied again: 1 + 3; NMS only removes).
  * The output sizes are data dependent: the call synchronises the stream ONCE and returns them through
  * *num_boxes_out / *num_pairs_out (the reference synchronises dozens of times in this branch).
  * `out_source_row` (optional) tells which input row each output box is a copy of. */
@@ -254,7 +260,7 @@ typedef struct SttranObjclsSelect {
   const float* distribution;     /* [B,num_cols]          entry['distribution']       */
   const float* features;         /* [B,feat_dim] or NULL  entry['features']           */
   const int64_t* pred_labels;    /* [B]                   entry['pred_labels'] (the detector's) */
-  int64_t capacity;              /* rows of every out_* array, >= 8 * num_boxes       */
+  int64_t capacity;              /* rows of every out_* array, >= 4 * num_boxes       */
   float* out_boxes;              /* [capacity,5]                                      */
   float* out_distribution;       /* [capacity,num_cols]                               */
   float* out_features;           /* [capacity,feat_dim] or NULL                       */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsttran_hip.so")
 
 STTRAN_OK = 0
-ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "WEIGHTS", 5: "ORDER", 6: "LIMIT"}
+ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "WEIGHTS", 5: "ORDER", 6: "LIMIT", 7: "INDEX"}
 MODE = {"predcls": 0, "sgcls": 1, "sgdet": 2}
 MODEL_STTRAN, MODEL_DSG_DETR = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_I32 = 0, 1, 2

@@ -130,7 +130,8 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
 // the lengths are only known on the device (len_bound >= every one of them): one launch per length class, no read-back
 hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
                                     int len_bound, float* out, int64_t ldo, int dim, int nhead);
-constexpr int kAttnMaxKeys = 480;   // longest sequence the attention kernel accepts
+constexpr int kAttnChunkKeys = 480;  // keys per pass of the general attention kernel's LDS score block (longer sequences:
+                                     // several passes with a running softmax -- no limit on the sequence length)
 hipError_t launch_gather_rows(hipStream_t s, const float* src, int64_t lds, const int* idx, float* dst, int64_t ldd,
                               int64_t rows, int dim);
 
@@ -145,7 +146,7 @@ hipError_t launch_objcls_prep(hipStream_t s, const ChunkTable& tab, const float*
 
 // ---- SGDet without weak supervision (lib/sttran.py:185-283): kernels_objcls.hip ------------------------
 size_t objcls_scratch_bytes(int64_t B, int T);
-// clean_class + per-(frame, class) NMS + labels / scores / human / pairs.  Outputs need 8 * B rows (pairs: 8 * B too).
+// clean_class + per-(frame, class) NMS + labels / scores / human / pairs.  Outputs need 4 * B rows (pairs: 4 * B too).
 // Synchronises `s` once to return {rows, pairs, status} in host_out.
 hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* dist, const float* feats,
                                 const int64_t* labels, int64_t B, int T, int ncol, int F, float thr, int ge, int64_t capacity,

@@ -40,97 +40,121 @@ __device__ __forceinline__ void stage_head_rows(float* dst, const float* __restr
   }
 }
 
+// Keys are processed in chunks of `kc` (<= kAttnChunkKeys, what the LDS score block holds) with a running row maximum
+// and row sum (online softmax): a sequence of ANY length is handled -- the reference has no limit
+// (lib/transformer.py:130-163 pads to the longest frame / window whatever it is).  A sequence that fits one chunk
+// (<= 480 keys: everything this kernel saw in rounds 1-2) takes exactly the former single-pass arithmetic.
 __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
-                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int skp, int len_lo, int len_hi) {
+                 float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int kc, int len_lo, int len_hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
   const int L = seq_len[s];
-  // (len_lo, len_hi]: shorter sequences belong to another launch (launch_attention_classes); longer ones than the LDS was
-  // sized for are skipped (the layout kernel has flagged them)
+  // (len_lo, len_hi]: shorter sequences belong to another launch (launch_attention_classes)
   if (q0 >= L || L <= len_lo || L > len_hi) return;
   const int base = seq_off[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ps = skp + 4;                       // score row stride
+  const int ps = kc + 4;                        // score row stride
   float* Qs = smem;                             // [32][260]
   float* KVs = Qs + 32 * kQStride;              // [32][260]
-  float* Ps = KVs + 32 * kQStride;              // [32][skp+4]
-  float* rinv = Ps + 32 * ps;                   // [32]
+  float* Ps = KVs + 32 * kQStride;              // [32][kc+4]
+  float* rmax = Ps + 32 * ps;                   // [32] running maximum of each query row
+  float* rsum = rmax + 32;                      // [32] running sum of exp(score - rmax)
+  float* ralpha = rsum + 32;                    // [32] exp(old maximum - new maximum) of the current chunk
   const int64_t ld = 3 * (int64_t)dim;
   const float* qp = qkv + (int64_t)base * ld + h * hd;
-  const int nkt = (L + 31) / 32;
 
   stage_head_rows(Qs, qp, ld, q0, min(32, L - q0), hd, scale, tid);
+  if (tid < 32) { rmax[tid] = -INFINITY; rsum[tid] = 0.f; }
 
-  // ---- phase 1: scores ------------------------------------------------------------------
   const int qi = wave >> 1, kj = wave & 1, l15 = lane & 15, g = lane >> 4;
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();                            // previous tile's reads of KVs are done
-    stage_head_rows(KVs, qp + dim, ld, kt * 32, min(32, L - kt * 32), hd, 1.f, tid);
-    __syncthreads();
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    const float* ar = Qs + (qi * 16 + l15) * kQStride + 4 * g;
-    const float* br = KVs + (kj * 16 + l15) * kQStride + 4 * g;
-#pragma unroll 4
-    for (int kb = 0; kb < kHdPad / 16; ++kb) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ar + kb * 16);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(br + kb * 16);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1, 0, 0, 0);
-    }
-    // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kt * 32 + kj * 16 + l15] = c0[e] + c1[e];
-  }
-  __syncthreads();
-
-  // ---- softmax over keys [0, L) of each of the 32 rows; 8 rows per wave --------------------
-  for (int r = wave * 8; r < wave * 8 + 8; ++r) {
-    float* pr = Ps + r * ps;
-    float m = -INFINITY;
-    for (int c = lane; c < L; c += 64) m = fmaxf(m, pr[c]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    float sum = 0.f;
-    for (int c = lane; c < nkt * 32; c += 64) {
-      const float e = (c < L) ? expf(pr[c] - m) : 0.f;
-      pr[c] = e;
-      sum += e;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) rinv[r] = 1.f / sum;
-  }
-
-  // ---- phase 2: O = P V -------------------------------------------------------------------
   const int fr = lane & 31, fh = lane >> 5;
   f32x16 o0, o1;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
   const int d0 = wave * 64;                     // this wave's two 32-column output tiles
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    stage_head_rows(KVs, qp + 2 * dim, ld, kt * 32, min(32, L - kt * 32), hd, 1.f, tid);
-    __syncthreads();
+
+  for (int k0 = 0; k0 < L; k0 += kc) {
+    const int Lc = min(kc, L - k0);             // keys of this chunk
+    const int nkt = (Lc + 31) / 32;
+    // ---- phase 1: scores of the chunk -----------------------------------------------------
+    for (int kt = 0; kt < nkt; ++kt) {
+      __syncthreads();                          // previous tile's reads of KVs are done
+      stage_head_rows(KVs, qp + dim, ld, k0 + kt * 32, min(32, Lc - kt * 32), hd, 1.f, tid);
+      __syncthreads();
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+      const float* ar = Qs + (qi * 16 + l15) * kQStride + 4 * g;
+      const float* br = KVs + (kj * 16 + l15) * kQStride + 4 * g;
+#pragma unroll 4
+      for (int kb = 0; kb < kHdPad / 16; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ar + kb * 16);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(br + kb * 16);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c1, 0, 0, 0);
+      }
+      // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + fr * ps + kt * 32 + kb * 8 + 4 * fh);
+      for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kt * 32 + kj * 16 + l15] = c0[e] + c1[e];
+    }
+    __syncthreads();
+
+    // ---- softmax over the chunk's keys of each of the 32 rows; 8 rows per wave ------------------
+    for (int r = wave * 8; r < wave * 8 + 8; ++r) {
+      float* pr = Ps + r * ps;
+      float m = rmax[r];
+      const float m_old = m;
+      for (int c = lane; c < Lc; c += 64) m = fmaxf(m, pr[c]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* vr = KVs + (kb * 8 + 4 * fh + e) * kQStride + d0 + fr;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[0], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[32], o1, 0, 0, 0);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float sum = 0.f;
+      for (int c = lane; c < nkt * 32; c += 64) {
+        const float e = (c < Lc) ? expf(pr[c] - m) : 0.f;
+        pr[c] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if (lane == 0) {
+        const float alpha = k0 ? expf(m_old - m) : 0.f;      // first chunk: nothing accumulated yet
+        ralpha[r] = alpha;
+        rmax[r] = m;
+        rsum[r] = k0 ? rsum[r] * alpha + sum : sum;
+      }
+    }
+
+    // ---- phase 2: O = O * alpha + P V over the chunk --------------------------------------------
+    for (int kt = 0; kt < nkt; ++kt) {
+      __syncthreads();                          // (first tile: also publishes the softmax results)
+      stage_head_rows(KVs, qp + 2 * dim, ld, k0 + kt * 32, min(32, Lc - kt * 32), hd, 1.f, tid);
+      if (kt == 0 && k0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float al = ralpha[(e & 3) + 8 * (e >> 2) + 4 * fh];
+          o0[e] *= al; o1[e] *= al;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ps + fr * ps + kt * 32 + kb * 8 + 4 * fh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* vr = KVs + (kb * 8 + 4 * fh + e) * kQStride + d0 + fr;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[0], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], vr[32], o1, 0, 0, 0);
+        }
       }
     }
   }
+  __syncthreads();
   float* op = out + (int64_t)(base + q0) * ldo + h * hd;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int q = (e & 3) + 8 * (e >> 2) + 4 * fh;
     if (q0 + q < L) {
-      const float ri = rinv[q];
+      const float ri = 1.f / rsum[q];
       const int c0 = d0 + fr, c1 = d0 + 32 + fr;
       if (c0 < hd) op[(int64_t)q * ldo + c0] = o0[e] * ri;
       if (c1 < hd) op[(int64_t)q * ldo + c1] = o1[e] * ri;
@@ -355,7 +379,7 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || max_len <= 0) return hipSuccess;
   const int hd = dim / nhead;
-  if (hd > kHdPad - 2 || (hd & 1) || max_len > kAttnMaxKeys) return hipErrorInvalidValue;
+  if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)hd);
   if (max_len <= kAttnShortMax) {
     const int l16 = (max_len + 15) & ~15;
@@ -372,12 +396,12 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
   }
   // the long-sequence kernel computes every query row: q_begin is an optimisation hint only (rows before
   // it are never read by the caller), so it is simply not used here
-  const int skp = (max_len + 31) / 32 * 32;
-  const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
+  const int kc = std::min((max_len + 31) / 32 * 32, kAttnChunkKeys);      // keys per pass of the LDS score block
+  const int lds = (2 * 32 * kQStride + 32 * (kc + 4) + 96) * 4;
   hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
   if (e != hipSuccess) return e;
   dim3 grid((max_len + 31) / 32, nhead, num_seq);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp, 0, 1 << 30);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, kc, 0, 1 << 30);
   return hipGetLastError();
 }
 
@@ -390,7 +414,6 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
   if (num_seq <= 0 || len_bound <= 0) return hipSuccess;
   const int hd = dim / nhead;
   if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
-  if (len_bound > kAttnMaxKeys) len_bound = kAttnMaxKeys;      // longer sequences are skipped (and flagged by their producer)
   const float scale = 1.0f / sqrtf((float)hd);
   const int edges[3] = {0, 48, kAttnShortMax};
   for (int v = 0; v < 2; ++v) {
@@ -410,12 +433,12 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     if (e != hipSuccess) return e;
   }
   if (len_bound > kAttnShortMax) {
-    const int skp = (len_bound + 31) / 32 * 32;
-    const int lds = (2 * 32 * kQStride + 32 * (skp + 4) + 32) * 4;
+    const int kc = std::min((len_bound + 31) / 32 * 32, kAttnChunkKeys);
+    const int lds = (2 * 32 * kQStride + 32 * (kc + 4) + 96) * 4;
     hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
     if (e != hipSuccess) return e;
     dim3 grid((len_bound + 31) / 32, nhead, num_seq);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, skp,
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, kc,
                        kAttnShortMax, len_bound);
     return hipGetLastError();
   }

@@ -18,8 +18,7 @@ namespace {
 constexpr int kEvalThreads = 256;
 constexpr int kEvalTop = 50;            // R@50 is the deepest list the evaluator reads
 constexpr int kEvalMaxCols = 32;
-constexpr int kEvalMaxCand = 7488;      // rows * cols, 58.5 KB of float64 scores in LDS (26 cols: 96 pairs/frame)
-constexpr int kEvalMaxRows = 320;
+constexpr int kEvalMaxCand = 7488;      // rows * cols of ONE chunk, 58.5 KB of order keys in LDS (26 cols: 288 rows = 96 pairs)
 constexpr int kEvalKeysPerThread = (kEvalMaxCand + kEvalThreads - 1) / kEvalThreads;   // 30 order keys in registers
 
 struct EvalArgs {
@@ -145,12 +144,13 @@ __device__ void select_top(const uint64_t* key, int ncand, int (*part)[4], int& 
 }
 
 __global__ __launch_bounds__(kEvalThreads) void eval_recall_kernel(EvalArgs a) {
-  __shared__ uint64_t key[kEvalMaxCand];       // order key of subj_score * obj_score * predicate_score per (row, predicate)
-  __shared__ int rsub[kEvalMaxRows], robj[kEvalMaxRows];
-  __shared__ int sel[kEvalTop], top[kEvalTop];
+  __shared__ uint64_t key[kEvalMaxCand];       // order key of subj_score * obj_score * predicate_score per (row, predicate) of a chunk
+  __shared__ int sel[kEvalTop];
+  __shared__ uint64_t run_key[2][kEvalTop];     // the running top list, ordered (double-buffered across merges)
+  __shared__ int run_idx[2][kEvalTop];          // ... candidate index = row * ncol + predicate over the WHOLE frame
   __shared__ int pr_pred[kEvalTop], pr_cs[kEvalTop], pr_co[kEvalTop];   // the ordered predictions: predicate, classes,
   __shared__ float pr_box[kEvalTop][8];                                  // subject box | object box
-  __shared__ int part[2][4], nsel;
+  __shared__ int part[2][4], nsel, run_n[2];
   const int f = blockIdx.x, metric = blockIdx.y, tid = threadIdx.x;
   const int ncol = a.na + a.ns + a.nc;
   const int g_lo = a.gt_rel_off[f], g_hi = a.gt_rel_off[f + 1];
@@ -171,89 +171,116 @@ __global__ __launch_bounds__(kEvalThreads) void eval_recall_kernel(EvalArgs a) {
   }
   const int lo = block_total(c_lo, part, phase), hi = block_total(c_hi, part, phase);
   const int n = hi - lo;
-  const bool bad = 3 * n > kEvalMaxRows || 3 * n * ncol > kEvalMaxCand;
-  const int rows = bad ? 0 : 3 * n, ncand = rows * ncol;
-  if (bad && tid == 0) atomicOr(a.status, 1);
-  if (tid < kEvalTop) top[tid] = -1;
-  if (tid == 0) nsel = 0;
-
-  EVAL_STAMP(1);
-  // ---- the frame's relation rows: attention | spatial (subject and object swapped) | contacting -------
-  for (int r = tid; r < rows; r += kEvalThreads) {
+  const int rows = 3 * n;
+  const int chunk_rows = kEvalMaxCand / ncol;                 // 288 rows at 26 predicates
+  if (tid == 0) { run_n[0] = 0; run_n[1] = 0; }
+  int cur = 0;                                                // which half of run_* holds the list
+  // row r of the frame's [3n, ncol] table -> (subject, object) box rows; kind 1 (spatial) swaps them (:429-431)
+  auto row_boxes = [&](int r, int& sub, int& obj) {
     const int kind = r / n, p = lo + (r - kind * n);
     const int64_t p0 = a.pair_idx[2 * p], p1 = a.pair_idx[2 * p + 1];
     const bool oob = p0 < 0 || p0 >= a.B || p1 < 0 || p1 >= a.B;
-    if (oob) atomicOr(a.status, 2);
-    const int sub = oob ? 0 : (int)(kind == 1 ? p1 : p0), obj = oob ? 0 : (int)(kind == 1 ? p0 : p1);
-    rsub[r] = sub; robj[r] = obj;
-    // the row of the zero-padded [3n, ncol] score table (lib/evaluation_recall.py:436-441); the softmax of the
-    // attention logits (:400) is float32
-    float smax = 0.f, ssum = 1.f;
-    if (kind == 0) {
-      smax = a.att[(size_t)p * a.na];
-      for (int c = 1; c < a.na; ++c) smax = fmaxf(smax, a.att[(size_t)p * a.na + c]);
-      ssum = 0.f;
-      for (int c = 0; c < a.na; ++c) ssum += expf(a.att[(size_t)p * a.na + c] - smax);
-    }
-    float row[kEvalMaxCols];
-#pragma unroll
-    for (int c = 0; c < kEvalMaxCols; ++c) {
-      float v = 0.f;
-      if (kind == 0) { if (c < a.na) v = expf(a.att[(size_t)p * a.na + c] - smax) / ssum; }
-      else if (kind == 1) { if (c >= a.na && c < a.na + a.ns) v = a.spa[(size_t)p * a.ns + (c - a.na)]; }
-      else { if (c >= a.na + a.ns && c < ncol) v = a.con[(size_t)p * a.nc + (c - a.na - a.ns)]; }
-      row[c] = v;
-    }
-    int arg = 0; float best = row[0];
-#pragma unroll
-    for (int c = 1; c < kEvalMaxCols; ++c) if (c < ncol && row[c] > best) { best = row[c]; arg = c; }   // first maximum
-    uint32_t v;
-    if (metric == 0) {                   // with graph constraint: the arg-max predicate of every row (:221-235)
-      v = 1u << arg;
-    } else if (metric == 1) {            // no constraint: every (row, predicate) entry (:330-340)
-      v = ncol == 32 ? 0xffffffffu : ((1u << ncol) - 1u);
-    } else {                             // semi constraint (:270-288)
-      const bool is_att = ((double)row[0] + (double)row[1]) > 0.0;
-      const bool is_multi = !is_att && ((((double)row[3] + (double)row[4]) > 0.0) || (((double)row[9] + (double)row[10]) > 0.0));
-      v = 0;
-      if (is_att) v = 1u << arg;
-      else if (is_multi) {
-#pragma unroll
-        for (int c = 0; c < kEvalMaxCols; ++c) if (c < ncol && row[c] > 0.5f) v |= 1u << c;
-      }
-    }
-    if (oob) v = 0;
-    const double op = oob ? 0.0 : (double)(a.obj_scores[sub] * a.obj_scores[obj]);   // float32 product, then float64 (:663-664)
-#pragma unroll
-    for (int c = 0; c < kEvalMaxCols; ++c)
-      if (c < ncol) key[r * ncol + c] = ((v >> c) & 1u) ? sortable(op * (double)row[c]) : 0;
-  }
-  __syncthreads();
+    sub = oob ? 0 : (int)(kind == 1 ? p1 : p0);
+    obj = oob ? 0 : (int)(kind == 1 ? p0 : p1);
+    return oob;
+  };
 
-  EVAL_STAMP(2);
-  // ---- the 50 best candidates (unordered) -> sel[0..nsel) ------------------------------------------------
-  if (ncand <= 4 * kEvalThreads) select_top<4>(key, ncand, part, phase, sel, &nsel);
-  else if (ncand <= 8 * kEvalThreads) select_top<8>(key, ncand, part, phase, sel, &nsel);
-  else if (ncand <= 16 * kEvalThreads) select_top<16>(key, ncand, part, phase, sel, &nsel);
-  else select_top<kEvalKeysPerThread>(key, ncand, part, phase, sel, &nsel);
-  __syncthreads();
-  EVAL_STAMP(3);
-  if (tid < nsel) {                      // order the selected ones: score descending, index ascending
-    const int i = sel[tid];
-    const uint64_t k = key[i];
-    int rank = 0;
-    for (int j = 0; j < nsel; ++j) {
-      const int i2 = sel[j];
-      const uint64_t k2 = key[i2];
-      rank += (k2 > k) || (k2 == k && i2 < i);
+  for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
+    const int crow = min(chunk_rows, rows - r0), ncand = crow * ncol;
+    __syncthreads();                                          // the previous chunk's keys / sel are no longer read
+    if (tid == 0) nsel = 0;
+    EVAL_STAMP(1);
+    // ---- the chunk's relation rows: attention | spatial (subject and object swapped) | contacting -------
+    for (int rl = tid; rl < crow; rl += kEvalThreads) {
+      const int r = r0 + rl;
+      const int kind = r / n, p = lo + (r - kind * n);
+      int sub, obj;
+      const bool oob = row_boxes(r, sub, obj);
+      if (oob) atomicOr(a.status, 2);
+      // the row of the zero-padded [3n, ncol] score table (lib/evaluation_recall.py:436-441); the softmax of the
+      // attention logits (:400) is float32
+      float smax = 0.f, ssum = 1.f;
+      if (kind == 0) {
+        smax = a.att[(size_t)p * a.na];
+        for (int c = 1; c < a.na; ++c) smax = fmaxf(smax, a.att[(size_t)p * a.na + c]);
+        ssum = 0.f;
+        for (int c = 0; c < a.na; ++c) ssum += expf(a.att[(size_t)p * a.na + c] - smax);
+      }
+      float row[kEvalMaxCols];
+#pragma unroll
+      for (int c = 0; c < kEvalMaxCols; ++c) {
+        float v = 0.f;
+        if (kind == 0) { if (c < a.na) v = expf(a.att[(size_t)p * a.na + c] - smax) / ssum; }
+        else if (kind == 1) { if (c >= a.na && c < a.na + a.ns) v = a.spa[(size_t)p * a.ns + (c - a.na)]; }
+        else { if (c >= a.na + a.ns && c < ncol) v = a.con[(size_t)p * a.nc + (c - a.na - a.ns)]; }
+        row[c] = v;
+      }
+      int arg = 0; float best = row[0];
+#pragma unroll
+      for (int c = 1; c < kEvalMaxCols; ++c) if (c < ncol && row[c] > best) { best = row[c]; arg = c; }   // first maximum
+      uint32_t v;
+      if (metric == 0) {                   // with graph constraint: the arg-max predicate of every row (:221-235)
+        v = 1u << arg;
+      } else if (metric == 1) {            // no constraint: every (row, predicate) entry (:330-340)
+        v = ncol == 32 ? 0xffffffffu : ((1u << ncol) - 1u);
+      } else {                             // semi constraint (:270-288)
+        const bool is_att = ((double)row[0] + (double)row[1]) > 0.0;
+        const bool is_multi = !is_att && ((((double)row[3] + (double)row[4]) > 0.0) || (((double)row[9] + (double)row[10]) > 0.0));
+        v = 0;
+        if (is_att) v = 1u << arg;
+        else if (is_multi) {
+#pragma unroll
+          for (int c = 0; c < kEvalMaxCols; ++c) if (c < ncol && row[c] > 0.5f) v |= 1u << c;
+        }
+      }
+      if (oob) v = 0;
+      const double op = oob ? 0.0 : (double)(a.obj_scores[sub] * a.obj_scores[obj]);   // float32 product, then float64 (:663-664)
+#pragma unroll
+      for (int c = 0; c < kEvalMaxCols; ++c)
+        if (c < ncol) key[rl * ncol + c] = ((v >> c) & 1u) ? sortable(op * (double)row[c]) : 0;
     }
-    top[rank] = i;
+    __syncthreads();
+
+    EVAL_STAMP(2);
+    // ---- the chunk's 50 best candidates (unordered) -> sel[0..nsel), local indices -----------------------------
+    if (ncand <= 4 * kEvalThreads) select_top<4>(key, ncand, part, phase, sel, &nsel);
+    else if (ncand <= 8 * kEvalThreads) select_top<8>(key, ncand, part, phase, sel, &nsel);
+    else if (ncand <= 16 * kEvalThreads) select_top<16>(key, ncand, part, phase, sel, &nsel);
+    else select_top<kEvalKeysPerThread>(key, ncand, part, phase, sel, &nsel);
+    __syncthreads();
+    EVAL_STAMP(3);
+    // ---- merge into the running list: rank of every entry of (running list + this chunk's selection) under
+    //      (key descending, frame-wide candidate index ascending); the first 50 survive, already in order ----
+    {
+      const int nrun = run_n[cur], ns = nsel, tot = nrun + ns;
+      const int nxt = cur ^ 1;
+      if (tid < tot) {
+        const bool from_run = tid < nrun;
+        const uint64_t k = from_run ? run_key[cur][tid] : key[sel[tid - nrun]];
+        const int i = from_run ? run_idx[cur][tid] : r0 * ncol + sel[tid - nrun];
+        int rank = 0;
+        for (int j = 0; j < nrun; ++j) {
+          const uint64_t k2 = run_key[cur][j];
+          rank += (k2 > k) || (k2 == k && run_idx[cur][j] < i);
+        }
+        for (int j = 0; j < ns; ++j) {
+          const uint64_t k2 = key[sel[j]];
+          const int i2 = r0 * ncol + sel[j];
+          rank += (k2 > k) || (k2 == k && i2 < i);
+        }
+        if (rank < kEvalTop) { run_key[nxt][rank] = k; run_idx[nxt][rank] = i; }
+      }
+      if (tid == 0) run_n[nxt] = min(tot, kEvalTop);
+      cur = nxt;
+    }
   }
   __syncthreads();
   EVAL_STAMP(4);
-
-  if (tid < kEvalTop && top[tid] >= 0) {
-    const int i = top[tid], r = i / ncol, sub = rsub[r], obj = robj[r];
+  const int ntop = run_n[cur];
+  if (tid < ntop) {
+    const int i = run_idx[cur][tid], r = i / ncol;
+    int sub, obj;
+    row_boxes(r, sub, obj);
     pr_pred[tid] = i - r * ncol;
     pr_cs[tid] = (int)a.classes[sub]; pr_co[tid] = (int)a.classes[obj];
 #pragma unroll
@@ -263,7 +290,6 @@ __global__ __launch_bounds__(kEvalThreads) void eval_recall_kernel(EvalArgs a) {
     }
   }
   __syncthreads();
-  const int ntop = nsel;
 
   EVAL_STAMP(5);
   // ---- one ground-truth relation per thread against the ordered list (:731-773) ------------------------
@@ -299,6 +325,7 @@ hipError_t launch_eval_recall(hipStream_t s, const float* att, const float* spa,
   return hipGetLastError();
 }
 
+// pairs of one frame that fit ONE pass of the key buffer; larger frames are chunked (no limit)
 int eval_max_pairs_per_frame(int ncol) { return ncol > 0 ? (kEvalMaxCand / ncol) / 3 : 0; }
 
 }  // namespace sttran

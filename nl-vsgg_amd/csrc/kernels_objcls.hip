@@ -21,7 +21,9 @@ namespace sttran {
 namespace {
 
 constexpr int kOcMaxCols = 64;        // class-distribution columns (36 in the reference)
-constexpr int kOcMaxFrameBoxes = 1024; // expanded boxes per frame the NMS kernel holds in LDS
+constexpr int kOcExpand = 4;           // copies one input box can have after clean_class(5), (8), (17): itself + one per pass,
+                                      // each pass copying only the newest copy of a chain (label c -> c' -> c'')
+constexpr int kOcMaxFrameBoxes = 1024; // expanded boxes per frame the NMS kernel holds in LDS (larger frames: global scratch)
 
 // arg-max over the columns of a distribution row with the masked columns reading 0 (first maximum wins, like
 // torch.argmax on distinct values)
@@ -48,16 +50,27 @@ __global__ void objcls_frame_ranges_kernel(const float* __restrict__ boxes, int 
   fstart[f] = lo;
 }
 
+// The frame ranges above need the rows sorted by frame id, every id inside [0, T) (the reference selects rows with
+// `boxes[:, 0] == i` and accepts any order, lib/sttran.py:59-62,205-207): checked here, status bit 1 otherwise
+__global__ void objcls_check_order_kernel(const float* __restrict__ boxes, int B, int T, int* __restrict__ status) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const float f = boxes[(int64_t)r * 5];
+  const bool bad = !(f >= 0.f) || !(f < (float)T) || f != floorf(f) || (r + 1 < B && boxes[(int64_t)(r + 1) * 5] < f);
+  if (bad) atomicOr(status, 2);
+}
+
 // clean_class(5), clean_class(8), clean_class(17) of one frame per thread (lib/sttran.py:52-85,197-199): after each
 // pass the frame's list is [what it was ..., a copy of every box whose label is the class, with that class's column
-// zeroed and the label re-derived by arg-max].  Capacity 8 x the frame's input boxes (each pass at most doubles).
+// zeroed and the label re-derived by arg-max].  Capacity 4 x the frame's input boxes: a pass copies an entry only if its
+// label is the pass's class, and a copy's new label can only match a LATER pass, so a box has at most 1 + 3 entries.
 __global__ void objcls_expand_kernel(const float* __restrict__ dist, const int64_t* __restrict__ labels, int ncol, int T,
                                      const int* __restrict__ fstart, int* __restrict__ ent_src, uint64_t* __restrict__ ent_mask,
                                      int* __restrict__ ent_label, int* __restrict__ n1) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= T) return;
   const int r0 = fstart[f], r1 = fstart[f + 1];
-  const int64_t base = (int64_t)8 * r0;
+  const int64_t base = (int64_t)kOcExpand * r0;
   int n = 0;
   for (int r = r0; r < r1; ++r, ++n) {
     ent_src[base + n] = r; ent_mask[base + n] = 0; ent_label[base + n] = (int)labels[r];
@@ -95,26 +108,25 @@ __device__ __forceinline__ float box_iou_inclusive(const float* p, const float* 
 // ascending, score descending, position ascending) = the order in which lib/sttran.py:211-236 emits the per-class
 // groups; greedy suppression inside each class (nms.cu:96-118: a box is dropped when its IoU with an earlier kept box
 // of the class exceeds the threshold; `ge` selects the CPU flavour's >=, nms_cpu.cpp:62).
-__global__ void __launch_bounds__(256)
-objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dist, int ncol, const int* __restrict__ fstart,
-                  const int* __restrict__ ent_src, const uint64_t* __restrict__ ent_mask, const int* __restrict__ n1,
-                  float thr, int ge, int* __restrict__ kept, int* __restrict__ n2, int* __restrict__ status) {
-  __shared__ float bx[kOcMaxFrameBoxes][4];
-  __shared__ float score[kOcMaxFrameBoxes];
-  __shared__ short cls[kOcMaxFrameBoxes];
-  __shared__ short order[kOcMaxFrameBoxes];
-  __shared__ unsigned char supp[kOcMaxFrameBoxes];
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int n = n1[f];
-  const int64_t base = (int64_t)8 * fstart[f];
-  if (n > kOcMaxFrameBoxes) {
-    if (tid == 0) { atomicOr(status, 1); n2[f] = 0; }
-    return;
-  }
+// The frame's tables (box, score, class, order, suppressed) live in LDS for up to 1 024 expanded boxes -- every frame a
+// detector with a few hundred proposals produces -- and in the caller's scratch for larger frames (same code, global
+// memory: slower, not limited; the reference has no limit).
+struct NmsTables {
+  float (*bx)[4];
+  float* score;
+  int* cls;
+  int* order;
+  unsigned char* supp;
+};
+__device__ void nms_frame(const NmsTables& t_, const float* __restrict__ boxes, const float* __restrict__ dist, int ncol,
+                          const int* __restrict__ ent_src, const uint64_t* __restrict__ ent_mask, int64_t base, int n, float thr,
+                          int ge, int* __restrict__ kept, int* __restrict__ n2f) {
+  const int tid = threadIdx.x;
+  float (*bx)[4] = t_.bx; float* score = t_.score; int* cls = t_.cls; int* order = t_.order; unsigned char* supp = t_.supp;
   for (int t = tid; t < n; t += 256) {
     const int src = ent_src[base + t];
     float s;
-    cls[t] = (short)argmax_masked(dist + (int64_t)src * ncol, ncol, ent_mask[base + t], 0, &s);
+    cls[t] = argmax_masked(dist + (int64_t)src * ncol, ncol, ent_mask[base + t], 0, &s);
     score[t] = s;
     for (int c = 0; c < 4; ++c) bx[t][c] = boxes[(int64_t)src * 5 + 1 + c];
     supp[t] = 0;
@@ -129,7 +141,7 @@ objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dis
       const float su = score[u];
       rank += (cu < ct) || (cu == ct && (su > st || (su == st && u < t)));
     }
-    order[rank] = (short)t;
+    order[rank] = t;
   }
   __syncthreads();
   for (int p = 0; p < n; ++p) {
@@ -151,8 +163,33 @@ objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dis
     int k = 0;
     for (int p = 0; p < n; ++p)
       if (!supp[p]) kept[base + k++] = order[p];
-    n2[f] = k;
+    *n2f = k;
   }
+}
+
+__global__ void __launch_bounds__(256)
+objcls_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ dist, int ncol, const int* __restrict__ fstart,
+                  const int* __restrict__ ent_src, const uint64_t* __restrict__ ent_mask, const int* __restrict__ n1,
+                  float thr, int ge, int* __restrict__ kept, int* __restrict__ n2, float* __restrict__ big_f,
+                  int* __restrict__ big_i, unsigned char* __restrict__ big_b) {
+  __shared__ float bx[kOcMaxFrameBoxes][4];
+  __shared__ float score[kOcMaxFrameBoxes];
+  __shared__ int cls[kOcMaxFrameBoxes];
+  __shared__ int order[kOcMaxFrameBoxes];
+  __shared__ unsigned char supp[kOcMaxFrameBoxes];
+  const int f = blockIdx.x;
+  const int n = n1[f];
+  const int64_t base = (int64_t)kOcExpand * fstart[f];
+  NmsTables t;
+  if (n <= kOcMaxFrameBoxes) {
+    t = NmsTables{bx, score, cls, order, supp};
+  } else {
+    // this frame's slice of the caller's scratch (8 entries per input box, like ent_*): [box 4 | score 1] floats,
+    // [class | order] ints, suppressed bytes
+    t = NmsTables{reinterpret_cast<float (*)[4]>(big_f + 5 * base), big_f + 5 * base + 4 * (int64_t)n, big_i + 2 * base,
+                  big_i + 2 * base + n, big_b + base};
+  }
+  nms_frame(t, boxes, dist, ncol, ent_src, ent_mask, base, n, thr, ge, kept, n2 + f);
 }
 
 // exclusive scan of per-frame counts by one thread (T is a few hundred at most) + the grand total
@@ -180,7 +217,7 @@ objcls_write_rows_kernel(const float* __restrict__ boxes, const float* __restric
     if (off2[mid] <= r) lo = mid; else hi = mid;
   }
   const int f = lo;
-  const int64_t base = (int64_t)8 * fstart[f];
+  const int64_t base = (int64_t)kOcExpand * fstart[f];
   const int e = kept[base + (r - off2[f])];
   const int src = ent_src[base + e];
   const uint64_t m = ent_mask[base + e];
@@ -329,8 +366,9 @@ size_t objcls_scratch_bytes(int64_t B, int T) {
   size_t n = 0;
   auto add = [&](size_t b) { n += (b + 255) & ~size_t(255); };
   add((size_t)(T + 2) * 4);                       // fstart
-  add((size_t)8 * B * 4); add((size_t)8 * B * 8); add((size_t)8 * B * 4);   // ent_src / ent_mask / ent_label
-  add((size_t)8 * B * 4);                         // kept
+  add((size_t)kOcExpand * B * 4); add((size_t)kOcExpand * B * 8); add((size_t)kOcExpand * B * 4);   // ent_src / ent_mask / ent_label
+  add((size_t)kOcExpand * B * 4);                         // kept
+  add((size_t)kOcExpand * B * 5 * 4); add((size_t)kOcExpand * B * 2 * 4); add((size_t)kOcExpand * B);   // NMS tables of frames with more than 1 024 expanded boxes
   for (int i = 0; i < 5; ++i) add((size_t)(T + 2) * 4);   // n1, n2, off2, np, poff
   add(64);                                        // totals + status
   return n + 256;
@@ -345,10 +383,13 @@ hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* 
   if (ncol > kOcMaxCols || ncol < 2 || B <= 0 || T <= 0 || capacity < 1) return hipErrorInvalidValue;
   char* p = reinterpret_cast<char*>(scratch);
   int* fstart = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
-  int* ent_src = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
-  uint64_t* ent_mask = reinterpret_cast<uint64_t*>(carve(p, (size_t)8 * B * 8));
-  int* ent_label = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
-  int* kept = reinterpret_cast<int*>(carve(p, (size_t)8 * B * 4));
+  int* ent_src = reinterpret_cast<int*>(carve(p, (size_t)kOcExpand * B * 4));
+  uint64_t* ent_mask = reinterpret_cast<uint64_t*>(carve(p, (size_t)kOcExpand * B * 8));
+  int* ent_label = reinterpret_cast<int*>(carve(p, (size_t)kOcExpand * B * 4));
+  int* kept = reinterpret_cast<int*>(carve(p, (size_t)kOcExpand * B * 4));
+  float* big_f = reinterpret_cast<float*>(carve(p, (size_t)kOcExpand * B * 5 * 4));
+  int* big_i = reinterpret_cast<int*>(carve(p, (size_t)kOcExpand * B * 2 * 4));
+  unsigned char* big_b = reinterpret_cast<unsigned char*>(carve(p, (size_t)kOcExpand * B));
   int* n1 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
   int* n2 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
   int* off2 = reinterpret_cast<int*>(carve(p, (size_t)(T + 2) * 4));
@@ -358,12 +399,13 @@ hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* 
   hipError_t e = hipMemsetAsync(totals, 0, 64, s);
   if (e != hipSuccess) return e;
   const int tb = 128, tg = (T + 1 + tb - 1) / tb;
+  hipLaunchKernelGGL(objcls_check_order_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, boxes, (int)B, T, totals + 2);
   hipLaunchKernelGGL(objcls_frame_ranges_kernel, dim3(tg), dim3(tb), 0, s, boxes, (int)B, T, fstart);
   hipLaunchKernelGGL(objcls_expand_kernel, dim3(tg), dim3(tb), 0, s, dist, labels, ncol, T, fstart, ent_src, ent_mask, ent_label, n1);
   hipLaunchKernelGGL(objcls_nms_kernel, dim3(T), dim3(256), 0, s, boxes, dist, ncol, fstart, ent_src, ent_mask, n1, thr, ge, kept,
-                     n2, totals + 2);
+                     n2, big_f, big_i, big_b);
   hipLaunchKernelGGL(objcls_scan_kernel, dim3(1), dim3(64), 0, s, n2, T, off2, totals);
-  const int64_t rows_cap = std::min<int64_t>(capacity, 8 * B);
+  const int64_t rows_cap = std::min<int64_t>(capacity, kOcExpand * B);
   hipLaunchKernelGGL(objcls_write_rows_kernel, dim3((unsigned)rows_cap), dim3(256), 0, s, boxes, dist, feats, ncol, F, T, fstart,
                      ent_src, ent_mask, kept, off2, o_boxes, o_dist, o_feats, o_score, o_label, o_src);
   hipLaunchKernelGGL(objcls_human_kernel, dim3(tg), dim3(tb), 0, s, o_dist, ncol, T, off2, o_human);

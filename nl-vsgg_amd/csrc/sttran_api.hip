@@ -947,10 +947,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     } else {
       build_layout(counts, clips, P, buf, h->lay);
     }
-    // (device-built class sequences: max_dec is only the largest clip; a sequence over the limit is flagged by the
-    //  layout kernel and reported by sttran_sync_check)
-    if (h->lay.max_enc > kAttnMaxKeys || (!h->lay.dsg_device && h->lay.max_dec > kAttnMaxKeys))
-      return fail(h, STTRAN_ERR_LIMIT, "forward: a frame/window exceeds the attention key limit");
+    // (no limit on the pairs of a frame / window / class sequence: the attention streams its keys in chunks)
     if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
     if ((rc = upload_staged(h, s, buf.data(), buf.size() * 4, h->idx.p))) return rc;
     h->cached_P = host_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
@@ -1055,7 +1052,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     const int64_t Kseq = L.n_dec_seq;
     int* d = h->dsg.as<int32_t>();
     HIPCK(launch_dsg_layout(s, nullptr, nullptr, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P, 400,
-                            kAttnMaxKeys, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, dsg_scratch,
+                            1 << 30, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, dsg_scratch,
                             h->err_flag, L.max_dec));
   }
   // subject / object rows of `features` gathered by element offset (one chunk per clip: GemmOperand::rowoff)
@@ -1227,8 +1224,8 @@ int sttran_sync_check(SttranHandle* h, void* stream) {
   HIPCK(hipMemcpy(&flag, h->err_flag, 4, hipMemcpyDeviceToHost));
   if (flag) {
     HIPCK(hipMemset(h->err_flag, 0, 4));
-    if (flag & 1) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx or labels out of range (values were clamped)");
-    return fail(h, STTRAN_ERR_LIMIT, "forward: a class sequence has more than 400 frames or exceeds the attention key limit");
+    if (flag & 1) return fail(h, STTRAN_ERR_INDEX, "forward: pair_idx or labels out of range (values were clamped)");
+    return fail(h, STTRAN_ERR_LIMIT, "forward: a class sequence spans more than 400 frames (the reference's positional-encoding table, lib/dsg_detr.py:25-48, has 400 rows)");
   }
   return STTRAN_OK;
 }
@@ -1273,7 +1270,7 @@ int64_t sttran_objcls_scratch_bytes(int64_t num_boxes, int32_t num_frames) {
 int sttran_objcls_select(const SttranObjclsSelect* a, int64_t* num_boxes_out, int64_t* num_pairs_out, void* stream) {
   if (!a || a->struct_size != sizeof(SttranObjclsSelect) || !num_boxes_out || !num_pairs_out) return STTRAN_ERR_INVALID;
   if (a->num_boxes <= 0 || a->num_frames <= 0) return STTRAN_ERR_EMPTY;
-  if (a->num_boxes > (1 << 26) || a->num_cols < 2 || a->num_cols > 64 || a->feat_dim < 0 || a->capacity < 8 * a->num_boxes)
+  if (a->num_boxes > (1 << 26) || a->num_cols < 2 || a->num_cols > 64 || a->feat_dim < 0 || a->capacity < 4 * a->num_boxes)
     return STTRAN_ERR_INVALID;
   if (!a->boxes || !a->distribution || !a->pred_labels || !a->out_boxes || !a->out_distribution || !a->out_pred_scores ||
       !a->out_pred_labels || !a->out_pair_idx || !a->out_im_idx || !a->out_human_idx || !a->scratch ||
@@ -1286,7 +1283,7 @@ int sttran_objcls_select(const SttranObjclsSelect* a, int64_t* num_boxes_out, in
                                       a->out_boxes, a->out_distribution, a->out_features, a->out_pred_scores, a->out_pred_labels,
                                       a->out_source_row, a->out_pair_idx, a->out_im_idx, a->out_human_idx, a->scratch, host);
   if (e != hipSuccess) return STTRAN_ERR_HIP;
-  if (host[2]) return STTRAN_ERR_LIMIT;            // a frame holds more than 1024 expanded boxes
+  if (host[2] & 2) return STTRAN_ERR_ORDER;        // boxes not sorted by frame id, or a frame id outside [0, num_frames)
   *num_boxes_out = host[0];
   *num_pairs_out = host[1];
   return STTRAN_OK;
@@ -1413,7 +1410,7 @@ int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int6
   if (!pair_idx || !labels || !clip_start || !dec_off || !dec_len || !dec_src || !need || !out_src || !scratch4p || !err_flag)
     return STTRAN_ERR_INVALID;
   return launch_dsg_layout(reinterpret_cast<hipStream_t>(stream), pair_idx, labels, (int)num_boxes, clip_start, num_clips,
-                           num_classes, (int)num_pairs, pe_rows, kAttnMaxKeys, dec_off, dec_len, dec_src, need, out_src, scratch4p,
+                           num_classes, (int)num_pairs, pe_rows, 1 << 30, dec_off, dec_len, dec_src, need, out_src, scratch4p,
                            err_flag, (int)std::min<int64_t>(num_pairs, 6144)) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 

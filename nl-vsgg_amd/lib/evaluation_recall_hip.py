@@ -257,8 +257,6 @@ class SceneGraphEvaluator_HIP(SceneGraphEvaluator):
         pending, self._pending = self._pending, []
         status = int(self._status.item())                                  # synchronises
         self._status.zero_()
-        if status & 1:
-            raise nat.SttranError(6, f"a frame has more than {self.max_pairs_per_frame} pairs")
         if status & 2:
             raise IndexError("pair_idx out of range of boxes")
         lazy = []                                  # consecutive small tables: one concatenated copy-back

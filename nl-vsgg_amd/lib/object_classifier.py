@@ -31,9 +31,11 @@ def roi_align(fmaps, rois, pooled=7, spatial_scale=1.0 / 16.0, sampling_ratio=0)
     T, Cc, H, W = (int(v) for v in fmaps.shape)
     P = int(rois.shape[0])
     out = torch.empty((P, Cc, pooled, pooled), dtype=torch.float32, device=fmaps.device)
-    stream = torch.cuda.current_stream(fmaps.device).cuda_stream
-    rc = lib.sttran_roi_align(C.c_void_p(fmaps.data_ptr()), T, Cc, H, W, C.c_void_p(rois.data_ptr()), P, pooled,
-                              float(spatial_scale), int(sampling_ratio), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    # the entry point has no handle (and so no device of its own): launch under the tensors' device, on its stream
+    with torch.cuda.device(fmaps.device):
+        stream = torch.cuda.current_stream(fmaps.device).cuda_stream
+        rc = lib.sttran_roi_align(C.c_void_p(fmaps.data_ptr()), T, Cc, H, W, C.c_void_p(rois.data_ptr()), P, pooled,
+                                  float(spatial_scale), int(sampling_ratio), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
     nat.check(lib, None, rc)
     return out
 
@@ -52,8 +54,15 @@ def sgdet_select(entry, nms_threshold=0.6, nms_ge=False, pooled=7, spatial_scale
     B, ncol, F = int(boxes.shape[0]), int(dist.shape[1]), int(feats.shape[1])
     if tuple(boxes.shape) != (B, 5) or dist.shape[0] != B or feats.shape[0] != B or tuple(labels.shape) != (B,) or B == 0:
         raise ValueError("boxes [B,5], distribution [B,C-1], features [B,F] and pred_labels [B] must agree on B > 0")
-    T = int(entry["fmaps"].shape[0]) if "fmaps" in entry else int(boxes[-1, 0].item()) + 1
-    cap = 8 * B
+    T = int(entry["fmaps"].shape[0]) if "fmaps" in entry else int(boxes[:, 0].max().item()) + 1
+    return _select(lib, entry, boxes, dist, feats, labels, B, ncol, F, T, nms_threshold, nms_ge, pooled, spatial_scale,
+                   sampling_ratio, mask_size, retried=False)
+
+
+def _select(lib, entry, boxes, dist, feats, labels, B, ncol, F, T, nms_threshold, nms_ge, pooled, spatial_scale, sampling_ratio,
+            mask_size, retried):
+    dev, f32, i64 = boxes.device, torch.float32, torch.int64
+    cap = 4 * B             # a box has at most one copy per clean_class pass and only the newest copy is copied again: 1 + 3
     o = {"boxes": torch.empty((cap, 5), dtype=f32, device=dev), "distribution": torch.empty((cap, ncol), dtype=f32, device=dev),
          "features": torch.empty((cap, F), dtype=f32, device=dev), "pred_scores": torch.empty((cap,), dtype=f32, device=dev),
          "pred_labels": torch.empty((cap,), dtype=i64, device=dev), "pair_idx": torch.empty((cap, 2), dtype=i64, device=dev),
@@ -69,14 +78,28 @@ def sgdet_select(entry, nms_threshold=0.6, nms_ge=False, pooled=7, spatial_scale
     a.out_pair_idx, a.out_im_idx, a.out_human_idx = o["pair_idx"].data_ptr(), o["im_idx"].data_ptr(), o["human_idx"].data_ptr()
     a.scratch = scratch.data_ptr()
     nb, npair = C.c_int64(0), C.c_int64(0)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    nat.check(lib, None, lib.sttran_objcls_select(C.byref(a), C.byref(nb), C.byref(npair), C.c_void_p(stream)))
+    with torch.cuda.device(dev):                                 # handle-less entry point: the tensors' device and stream
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.sttran_objcls_select(C.byref(a), C.byref(nb), C.byref(npair), C.c_void_p(stream))
+    if rc == 5 and not retried:
+        # STTRAN_ERR_ORDER: rows not grouped by ascending frame id.  The reference picks a frame's rows with
+        # `boxes[:, 0] == i` (lib/sttran.py:59-62,205-207), i.e. it takes any order and keeps the order inside a
+        # frame: a stable sort by frame id gives it the same rows in the same order
+        if float(boxes[:, 0].min().item()) < 0 or not bool((boxes[:, 0] == boxes[:, 0].floor()).all()):
+            raise ValueError("entry['boxes'][:, 0] must hold non-negative integer frame ids")
+        order = torch.sort(boxes[:, 0], stable=True).indices
+        Ts = max(T, int(boxes[:, 0].max().item()) + 1)
+        return _select(lib, entry, boxes[order].contiguous(), dist[order].contiguous(), feats[order].contiguous(),
+                       labels[order].contiguous(), B, ncol, F, Ts, nms_threshold, nms_ge, pooled, spatial_scale, sampling_ratio,
+                       mask_size, retried=True)
+    nat.check(lib, None, rc)
     B2, P2 = int(nb.value), int(npair.value)
+    # copies of the used rows: the 4 B-row work buffers (features alone: 32 KB per input box) are released on return
     for k in ("boxes", "distribution", "features", "pred_scores", "pred_labels"):
-        entry[k] = o[k][:B2]
-    entry["pair_idx"], entry["im_idx"] = o["pair_idx"][:P2], o["im_idx"][:P2]
+        entry[k] = o[k][:B2].clone()
+    entry["pair_idx"], entry["im_idx"] = o["pair_idx"][:P2].clone(), o["im_idx"][:P2].clone()
     entry["human_idx"] = o["human_idx"][:, None]                  # [b, 1] like lib/sttran.py:246
-    entry["_source_row"] = src[:B2]
+    entry["_source_row"] = src[:B2].clone()
     # union boxes + soft masks (f-1 kernel) and ROIAlign of the backbone feature maps
     from .union_boxes import union_boxes_and_masks
     if P2:

@@ -234,7 +234,7 @@ class STTran:
         last check (what `check_indices=True` does after every call)."""
         stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
         rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
-        if rc == 1:
+        if rc == 7:                                     # STTRAN_ERR_INDEX: what torch raises as an IndexError
             msg = self._lib.sttran_last_error(self._handle) or b""
             raise nat.SttranIndexError(rc, msg.decode("utf-8", "replace"))
         nat.check(self._lib, self._handle, rc)

@@ -125,7 +125,9 @@ def test_device_recall_identical_to_reference(case, golden_dir):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("counts,jitter", [([11] * 16, 0.0), ([11] * 16, 25.0), ([3, 1, 4, 2, 2], 25.0), ([1], 10.0),
-                                           ([1, 2, 1], 0.0), ([35] * 8, 30.0), ([96, 5], 20.0)])
+                                           ([1, 2, 1], 0.0), ([35] * 8, 30.0), ([96, 5], 20.0),
+                                           # more pairs than one pass of the key buffer holds (96 at 26 predicates): chunked
+                                           ([97, 3], 20.0), ([300, 150, 7], 25.0), ([193, 192], 0.0), ([500], 15.0)])
 def test_device_hit_table_equals_host(counts, jitter):
     host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container()
     dev = _device_eval()
@@ -163,14 +165,17 @@ def test_device_eval_follows_model_output():
 
 
 @pytest.mark.gpu
-def test_device_eval_too_many_pairs_is_an_error():
-    from nl_vsgg_amd import _native as nat
+def test_device_eval_has_no_pairs_per_frame_limit():
+    """rounds 1-2 refused frames with more than 96 pairs (one pass of the 58.5 KB key buffer); a frame now goes through
+    the buffer in chunks whose top-50 lists are merged -- 300 pairs per frame, all three metrics, equal to the host"""
     dev = _device_eval()
-    assert dev.max_pairs_per_frame == 96
-    gt, pred = _clip(5, [97, 3])
+    assert dev.max_pairs_per_frame == 96                         # pairs per PASS, no longer a limit
+    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container()
+    gt, pred = _clip(5, [300, 300, 97, 96, 1], jitter=20.0, pred_seed=3)
     dev.evaluate_scene_graph(gt, _to_dev(pred))
-    with pytest.raises(nat.SttranError):
-        dev.flush()
+    host.evaluate_scene_graph(gt, pred)
+    host.calculate_mean_recall(); dev.calculate_mean_recall()     # flush: no error
+    _same_results(host.result_dict, dev.result_dict, "predcls")
 
 
 @pytest.mark.gpu

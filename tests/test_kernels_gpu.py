@@ -208,7 +208,9 @@ def _attn_ref(qkv, offs, lens, dim, nhead):
     return out
 
 
-@pytest.mark.parametrize("lens", [[1], [22] * 15, [70, 3, 35, 64, 33], [5, 0, 9], [129, 31], [480]])
+@pytest.mark.parametrize("lens", [[1], [22] * 15, [70, 3, 35, 64, 33], [5, 0, 9], [129, 31], [480],
+                                  # beyond one pass of the 480-key score block: chunks with a running softmax
+                                  [481], [600, 7, 1000], [1537]])
 def test_attention(lib, lens):
     dim, nhead = 1936, 8
     g = torch.Generator(device="cuda").manual_seed(sum(lens))
@@ -234,6 +236,26 @@ def test_attention_spiked_scores(lib):
     qkv = torch.randn(L, 3 * dim, device="cuda", generator=g)
     qkv[3, :dim] *= 40.0
     qkv[17, dim:2 * dim] = qkv[3, :dim] / 4
+    out = torch.empty(L, dim, device="cuda")
+    so = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sl = torch.full((1,), L, dtype=torch.int32, device="cuda")
+    assert lib.sttran_debug_attention(_p(qkv), _p(so), _p(sl), 1, L, _p(out), L, dim, nhead, None) == 0
+    torch.cuda.synchronize()
+    ref = _attn_ref(qkv, [0], [L], dim, nhead)
+    assert torch.isfinite(out).all()
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("spike_at", [5, 700, 1100])
+def test_attention_spiked_scores_across_chunks(lib, spike_at):
+    """1 200 keys = three passes of the score block: a key that dominates a query by a large margin sits in the first,
+    second or third pass, so the running maximum jumps (and earlier partial sums are scaled down to ~0) or later
+    passes contribute ~0 to a row whose maximum is already large"""
+    dim, nhead, L = 1936, 8, 1200
+    g = torch.Generator(device="cuda").manual_seed(spike_at)
+    qkv = torch.randn(L, 3 * dim, device="cuda", generator=g)
+    qkv[3, :dim] *= 40.0
+    qkv[spike_at, dim:2 * dim] = qkv[3, :dim] / 4
     out = torch.empty(L, dim, device="cuda")
     so = torch.zeros(1, dtype=torch.int32, device="cuda")
     sl = torch.full((1,), L, dtype=torch.int32, device="cuda")

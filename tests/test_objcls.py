@@ -182,3 +182,122 @@ def test_sttran_sgdet_without_wks_end_to_end():
     for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
         np.testing.assert_array_equal(out[k].cpu().numpy(), want[k].cpu().numpy())
         assert out[k].shape[0] == ref["pair_idx"].shape[0]
+
+
+@pytest.mark.gpu
+def test_hip_select_frames_beyond_the_lds_tables():
+    """a frame with more than 1 024 expanded boxes (the NMS kernel's LDS tables): rounds 1-2 refused it
+    (STTRAN_ERR_LIMIT), now its tables live in the caller's scratch -- same kernel code, bit-identical to the oracle"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.object_classifier import sgdet_select
+    e = syn.make_detector_entry(811, [1300, 40, 1100], feat_dim=8, fmap_channels=2)
+    ref = oc.objcls_select(e["boxes"], e["distribution"], e["features"], e["pred_labels"])
+    out = sgdet_select(_to_cuda(e))
+    torch.cuda.synchronize()
+    for k in INT_KEYS + EXACT_KEYS:
+        np.testing.assert_array_equal(out[k].cpu().numpy().reshape(np.asarray(ref[k]).shape), ref[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_hip_select_takes_boxes_in_any_order():
+    """the reference selects a frame's rows with `boxes[:, 0] == i` (lib/sttran.py:59-62,205-207): any row order, the
+    order inside a frame kept.  The kernels need rows grouped by frame (STTRAN_ERR_ORDER otherwise); the wrapper then
+    stable-sorts by frame id and the result equals the sorted input's"""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd import _native as nat
+    from nl_vsgg_amd.lib.object_classifier import sgdet_select
+    e = syn.make_detector_entry(812, [12, 9, 15, 7], feat_dim=16, fmap_channels=3)
+    want = sgdet_select(_to_cuda(e))
+    rng = np.random.default_rng(3)
+    # interleave the frames, keeping the order of the rows inside each frame
+    frame = e["boxes"][:, 0].astype(int)
+    by_frame = {f: list(np.nonzero(frame == f)[0]) for f in np.unique(frame)}
+    seq = rng.permutation(frame)                                         # which frame every output slot takes a row from
+    order = np.array([by_frame[f].pop(0) for f in seq])
+    assert not np.all(np.diff(e["boxes"][order, 0]) >= 0)
+    shuf = dict(e)
+    for k in ("boxes", "distribution", "features", "pred_labels"):
+        shuf[k] = e[k][order]
+    got = sgdet_select(_to_cuda(shuf))
+    torch.cuda.synchronize()
+    for k in INT_KEYS + EXACT_KEYS:
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), err_msg=k)
+    # the C ABI itself reports the order instead of silently mis-assigning rows
+    lib = nat.load()
+    d = _to_cuda(shuf)
+    B, T = len(order), 4
+    cap = 4 * B
+    f32, i64 = torch.float32, torch.int64
+    o = [torch.empty((cap, 5), dtype=f32, device="cuda"), torch.empty((cap, 36), dtype=f32, device="cuda"),
+         torch.empty((cap,), dtype=f32, device="cuda"), torch.empty((cap,), dtype=i64, device="cuda"),
+         torch.empty((cap, 2), dtype=i64, device="cuda"), torch.empty((cap,), dtype=f32, device="cuda"),
+         torch.zeros((T,), dtype=i64, device="cuda")]
+    nscr = int(lib.sttran_objcls_scratch_bytes(B, T))
+    scratch = torch.empty((nscr,), dtype=torch.uint8, device="cuda")
+    a = nat.SttranObjclsSelect(struct_size=C.sizeof(nat.SttranObjclsSelect), num_frames=T, num_boxes=B, num_cols=36, feat_dim=0,
+                               nms_threshold=0.6, nms_ge=0, capacity=cap, scratch_bytes=nscr)
+    a.boxes, a.distribution, a.pred_labels = d["boxes"].data_ptr(), d["distribution"].data_ptr(), d["pred_labels"].data_ptr()
+    a.out_boxes, a.out_distribution, a.out_pred_scores, a.out_pred_labels = (t.data_ptr() for t in o[:4])
+    a.out_pair_idx, a.out_im_idx, a.out_human_idx, a.scratch = o[4].data_ptr(), o[5].data_ptr(), o[6].data_ptr(), scratch.data_ptr()
+    nb, npair = C.c_int64(0), C.c_int64(0)
+    assert lib.sttran_objcls_select(C.byref(a), C.byref(nb), C.byref(npair), None) == 5      # STTRAN_ERR_ORDER
+    a.num_frames = 3                                                     # sorted rows, but frame id 3 >= num_frames
+    keep = _to_cuda(e)
+    a.boxes, a.distribution, a.pred_labels = keep["boxes"].data_ptr(), keep["distribution"].data_ptr(), keep["pred_labels"].data_ptr()
+    assert lib.sttran_objcls_select(C.byref(a), C.byref(nb), C.byref(npair), None) == 5
+
+
+@pytest.mark.gpu
+def test_sgdet_without_wks_through_both_evaluators():
+    """f-2 output at ~100+ boxes per frame (more pairs per frame than one pass of the device evaluator's key buffer
+    holds) -> relation transformer -> host AND device evaluator: identical result_dict.  Rounds 1-2: the model accepted
+    such a clip and the device evaluator then refused it."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from nl_vsgg_amd.lib.evaluation_recall import SceneGraphEvaluator
+    from nl_vsgg_amd.lib.evaluation_recall_hip import SceneGraphEvaluator_HIP
+    from nl_vsgg_amd.lib.sttran import STTran
+    classes = ["__background__"] + [f"c{i}" for i in range(36)]
+    att, spa, con = [f"a{i}" for i in range(3)], [f"s{i}" for i in range(6)], [f"c{i}" for i in range(17)]
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()}
+    m = STTran(mode="sgdet", is_wks=False, attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=classes,
+               enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", feat_dim=2048).to("cuda:0")
+    m.load_state_dict(sd, strict=False)
+    e = syn.make_detector_entry(402, [150, 130, 160], feat_dim=2048, fmap_channels=2048, fmap_hw=(12, 16), image_wh=(256.0, 192.0))
+    pred = m(_to_cuda(e))
+    counts = np.bincount(pred["im_idx"].cpu().numpy().astype(int), minlength=3)
+    assert counts.max() > 96, counts                                    # beyond one pass of the device evaluator
+    # ground truth in the AG_Test schema on the SELECTED boxes: the human of each frame + some of its objects
+    boxes = pred["boxes"].cpu().numpy(); labels = pred["pred_labels"].cpu().numpy(); pair = pred["pair_idx"].cpu().numpy()
+    rng = np.random.default_rng(9)
+    gt = []
+    for f in range(3):
+        pf = pair[pred["im_idx"].cpu().numpy().astype(int) == f]
+        human = int(pf[0, 0])
+        frame = [{"person_bbox": boxes[human, 1:][None, :].copy()}]
+        for o in rng.choice(pf[:, 1], size=min(6, len(pf)), replace=False):
+            frame.append({"class": int(labels[o]), "bbox": boxes[int(o), 1:].copy(),
+                          "attention_relationship": torch.tensor([int(rng.integers(0, 3))]),
+                          "spatial_relationship": torch.tensor(sorted(set(rng.integers(0, 6, 2).tolist()))),
+                          "contacting_relationship": torch.tensor(sorted(set(rng.integers(0, 17, 2).tolist())))})
+        gt.append(frame)
+    kw = dict(mode="sgdet", AG_object_classes=classes, AG_all_predicates=att + spa + con, AG_attention_predicates=att,
+              AG_spatial_predicates=spa, AG_contacting_predicates=con, iou_threshold=0.5)
+    host, dev = SceneGraphEvaluator(**kw), SceneGraphEvaluator_HIP(**kw)
+    host.register_container(); dev.register_container()
+    host.evaluate_scene_graph(gt, pred)
+    dev.evaluate_scene_graph(gt, pred)
+    host.calculate_mean_recall(); dev.calculate_mean_recall()
+    for t in ("recall", "recall_nogc", "semi_recall"):
+        for k in (10, 20, 50):
+            assert host.result_dict[f"sgdet_{t}"][k] == dev.result_dict[f"sgdet_{t}"][k], (t, k)
+    for t in ("mean_recall", "ng_mean_recall"):
+        for k in (10, 20, 50):
+            assert host.result_dict[f"sgdet_{t}_collect"][k] == dev.result_dict[f"sgdet_{t}_collect"][k], (t, k)
+    assert any(v > 0 for v in host.result_dict["sgdet_recall"][50])    # the ground truth is found at all

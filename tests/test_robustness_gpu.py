@@ -84,15 +84,17 @@ def test_reserve_between_forwards_keeps_results(weights):
 
 
 def test_failed_forward_does_not_poison_layout_cache(weights):
-    """forward(A) ok, forward(B) fails after its layout was built (a 600-token window: STTRAN_ERR_LIMIT),
+    """forward(A) ok, forward(B) fails after its counts were read (clip_num_frames that do not sum to the frames),
     forward(A) again: must not run A's device index maps with B's host-side offsets."""
     from nl_vsgg_amd._native import SttranError
     A = syn.make_entry(321, [4, 2, 5, 3])
     m = _model(weights)
     a = _run(m, A)
+    B = dict(_cuda_entry(syn.make_entry(322, [3, 3, 2])))
+    B["clip_num_frames"] = np.array([2, 2], dtype=np.int32)            # 4 frames claimed, 3 present
     with pytest.raises(SttranError) as ei:
-        m(_cuda_entry(syn.make_entry(322, [300, 300])))
-    assert ei.value.code == 6
+        m(B)
+    assert ei.value.code == 1
     b = _run(m, A)
     bad = dict(_cuda_entry(A)); bad["frame_counts"] = np.array([4, 2, 5, 4], dtype=np.int32)   # sums to 15 != 14
     with pytest.raises(SttranError):
