@@ -165,7 +165,10 @@ int sttran_missing_keys(SttranHandle* h, char* buf, int64_t buflen);
  * accumulation (csrc/gemm_bf16x3.h); measured error against fp64 no larger than the exact engine's.  The weights are
  * split once (at the next forward); activations are split on the fly.  Attention, the 7x7 mask convolution and the
  * small GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
-enum { STTRAN_GEMM_FP32_MFMA = 0, STTRAN_GEMM_BF16X3 = 1 };
+/* STTRAN_GEMM_BF16X3_ALL: the emulated engine for EVERY contraction it can take (N >= 128), whatever the row count -- the
+ * form the parity tests use so that small fixtures exercise it too (BF16X3 keeps launches under 512 rows on the exact engine,
+ * where the 256-row emulation tile would mostly compute padding). */
+enum { STTRAN_GEMM_FP32_MFMA = 0, STTRAN_GEMM_BF16X3 = 1, STTRAN_GEMM_BF16X3_ALL = 2 };
 int sttran_set_gemm_engine(SttranHandle* h, int32_t engine);
 /* Pre-size the workspace (otherwise grown on demand by forward; growth synchronises). */
 int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes);
@@ -315,8 +318,8 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
                              int32_t relu, int32_t tile_cfg, void* stream);
 /* EXPERIMENT (not on the product's default path): the same GEMM with fp32 EMULATED on the bf16 matrix pipe -- operands
  * split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation
- * (csrc/gemm_bf16x3.h).  W [N,K] fp32 (row stride ldw) is split into planes inside the call (untimed by the caller's
- * events only if it warms up first: the planes are cached per W pointer). */
+ * (csrc/gemm_bf16x3.h).  W [N,K] fp32 (row stride ldw) is split into planes inside every call; with
+ * STTRAN_X3_CACHE_PLANES=1 in the environment the planes of the last W pointer are reused (timing runs). */
 int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
                          const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                          int32_t relu, void* stream);

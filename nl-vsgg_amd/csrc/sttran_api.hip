@@ -273,7 +273,8 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     HIPCK(hipStreamSynchronize(s));
     HIPCK(h->slab.ensure(gemm_slab_bytes()));
   }
-  if (h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && M >= 512 && N >= 128 && !force_tile) {
+  if (h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && (M >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL) &&
+      N >= 128 && !force_tile) {
     // the weight (or a row range of it: the last decoder layer projects k|v and q separately) as bf16 planes
     for (auto& kv : h->w) {
       const Tensor& t = kv.second;
@@ -744,7 +745,7 @@ int sttran_finalize_weights(SttranHandle* h) {
 }
 
 int sttran_set_gemm_engine(SttranHandle* h, int32_t engine) {
-  if (!h || (engine != STTRAN_GEMM_FP32_MFMA && engine != STTRAN_GEMM_BF16X3)) return STTRAN_ERR_INVALID;
+  if (!h || (engine != STTRAN_GEMM_FP32_MFMA && engine != STTRAN_GEMM_BF16X3 && engine != STTRAN_GEMM_BF16X3_ALL)) return STTRAN_ERR_INVALID;
   h->gemm_engine = engine;
   return STTRAN_OK;
 }
@@ -846,7 +847,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
   h->prof_stream = s;
   int rc;
   if (!h->finalized && (rc = sttran_finalize_weights(h))) return rc;
-  if (h->gemm_engine == STTRAN_GEMM_BF16X3 && !h->planes_ready) {
+  if (h->gemm_engine != STTRAN_GEMM_FP32_MFMA && !h->planes_ready) {
     // split every GEMM weight into its three bf16 planes, once (also after a reload: load_tensor resets the flag)
     for (auto& kv : h->w) {
       Tensor& t = kv.second;
@@ -1070,7 +1071,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                                    h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
-    const bool x3 = h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && h->w4_planes && P * 49 >= 512;
+    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && h->w4_planes &&
+                    (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
                  x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_CONV2>,EpiConvRows>"
                     : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
@@ -1082,7 +1084,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
   }
   {
     const Tensor& wu = h->w["union_func1.weight"];
-    const bool x3 = h->gemm_engine == STTRAN_GEMM_BF16X3 && h->planes_ready && wu.planes && P * 49 >= 512;
+    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes &&
+                    (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
                  x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_UNION_FLAT>,EpiUnionRows>"
                     : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
@@ -1355,7 +1358,10 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
     planes_bytes = need;
     cached_w = nullptr;
   }
-  if (cached_w != Wt || cached_n != N || cached_k != K) {
+  // the planes are re-made on every call (a freed W may come back at the same address with other contents) unless the
+  // caller vouches for W staying put: STTRAN_X3_CACHE_PLANES=1 (tools/gemm_bench.py times the GEMM alone that way)
+  static const bool cache_ok = getenv("STTRAN_X3_CACHE_PLANES") && atoi(getenv("STTRAN_X3_CACHE_PLANES")) != 0;
+  if (!cache_ok || cached_w != Wt || cached_n != N || cached_k != K) {
     if (split_planes(s, Wt, ldw, (int)N, (int)K, planes, ldp) != hipSuccess) return STTRAN_ERR_HIP;
     cached_w = Wt; cached_n = N; cached_k = K;
   }

@@ -45,7 +45,7 @@ def box_iou_plus1(box, boxes):
 
 
 def match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, pred_boxes, pred_classes, predicate_scores,
-                      obj_scores, iou_thresh=0.5, iou_cache=None):
+                      obj_scores, iou_thresh=0.5, iou_cache=None, ties_by_index=False):
     """For every prediction (in descending order of subj_score * obj_score * predicate_score) the
     list of ground-truth relations it hits: equal class triple and both box IoUs >= iou_thresh
     (`lib/evaluation_recall.py:630-695,731-773`).
@@ -56,7 +56,10 @@ def match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, pred_boxes, pred
     if pred_rels.size == 0:
         return [[]]
     score = obj_scores[pred_rels[:, 0]] * obj_scores[pred_rels[:, 1]] * predicate_scores
-    order = score.argsort()[::-1]                     # same primitive as the reference: ties resolve alike
+    if ties_by_index:
+        order = np.argsort(-score, kind="stable")     # exactly equal scores: lower candidate index first (the device's rule)
+    else:
+        order = score.argsort()[::-1]                 # same primitive as the reference: ties resolve alike
     pr = pred_rels[order]
     iou = None if iou_cache is None else iou_cache.get("iou")
     if iou is None:
@@ -88,6 +91,14 @@ def _recall_at(hits, n_gt):
 
 
 class SceneGraphEvaluator:
+    # How predictions with EXACTLY equal scores are ordered.  "numpy" (default) = whatever `ndarray.argsort` does with
+    # them, which is what the reference does (lib/evaluation_recall.py:336,670: numpy's unstable sort on the host) -- the
+    # outcome is an accident of the sort implementation and of the array length.  "index" = lower candidate index
+    # (row-major over the frame's [3 n, predicates] table) first: the documented rule of the device evaluator, which
+    # cannot reproduce numpy's accident.  Equal float32 probabilities do occur (one frame in ~1 500 of the AG-shaped test
+    # set has such a pair straddling the R@10 cut), so device-vs-host comparisons run the host with "index".
+    tie_break = "numpy"
+
     def __init__(self, mode, AG_object_classes, AG_all_predicates, AG_attention_predicates, AG_spatial_predicates,
                  AG_contacting_predicates, iou_threshold=0.5, constraint=False, semithreshold=None):
         self.mode = mode
@@ -189,7 +200,7 @@ class SceneGraphEvaluator:
 
         def run(pred_rels, pscore):
             return match_predictions(gt_rels, gt_boxes, gt_classes, pred_rels, boxes, classes, pscore, obj_scores,
-                                     self.iou_threshold, cache)
+                                     self.iou_threshold, cache, ties_by_index=self.tie_break == "index")
 
         # with graph constraint: one predicate (the arg-max) per row (:221-235)
         hits_c = run(np.column_stack((rels, scores.argmax(1))), scores.max(1))
@@ -197,7 +208,7 @@ class SceneGraphEvaluator:
             self.result_dict[f"{m}_recall"][k].append(r)
         # no graph constraint: the 100 best (row, predicate) entries of obj-score-weighted scores (:351-356)
         overall = (obj_scores[rels].prod(1))[:, None] * scores
-        flat = np.argsort(-overall.ravel())[:100]
+        flat = np.argsort(-overall.ravel(), kind="stable" if self.tie_break == "index" else None)[:100]
         ri, ci = np.unravel_index(flat, overall.shape)
         hits_n = run(np.column_stack((rels[ri], ci)), scores[ri, ci])
         for k, (r, _) in _recall_at(hits_n, n_gt).items():

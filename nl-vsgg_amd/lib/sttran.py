@@ -77,7 +77,8 @@ class STTran:
         self.strict_inputs = False
         self._warned = set()
         # GEMM engine of the nn.Linear layers: "fp32" (default: exact fp32 MFMA) or "bf16x3" (EXPERIMENT: fp32 emulated
-        # on the bf16 matrix pipe with three bf16 planes per operand -- fp32-level error, ~1.4x the GEMM rate)
+        # on the bf16 matrix pipe with three bf16 planes per operand -- fp32-level error, ~1.4x the GEMM rate);
+        # "bf16x3_all" = the emulation for every contraction whatever its row count (parity tests on small fixtures)
         self.gemm_engine = "fp32"
         self._engine_set = None
         self._device = None
@@ -249,7 +250,7 @@ class STTran:
         self._ensure_handle()
         lib, h = self._lib, self._handle
         if self._engine_set != self.gemm_engine:
-            nat.check(lib, h, lib.sttran_set_gemm_engine(h, {"fp32": 0, "bf16x3": 1}[self.gemm_engine]))
+            nat.check(lib, h, lib.sttran_set_gemm_engine(h, {"fp32": 0, "bf16x3": 1, "bf16x3_all": 2}[self.gemm_engine]))
             self._engine_set = self.gemm_engine
         f32, i64 = torch.float32, torch.int64
         if isinstance(entry, PackedClips) and entry.by_pointer:

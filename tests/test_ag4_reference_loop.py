@@ -86,7 +86,8 @@ def test_oracle_reproduces_reference_loop(golden_dir):
 
 
 @pytest.mark.gpu
-def test_hip_reproduces_reference_loop(golden_dir):
+@pytest.mark.parametrize("engine", ["fp32", "bf16x3_all"])
+def test_hip_reproduces_reference_loop(golden_dir, engine):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -97,6 +98,7 @@ def test_hip_reproduces_reference_loop(golden_dir):
     model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=OBJ,
                    enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to("cuda:0")
     model.eval()
+    model.gemm_engine = engine            # exact fp32 MFMA, and the opt-in bf16x3 emulation: same checks, same tolerances
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     ev_host, ev_dev = SceneGraphEvaluator(**KW), SceneGraphEvaluator_HIP(**KW)
     ev_host.register_container(); ev_dev.register_container()

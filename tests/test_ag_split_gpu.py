@@ -31,7 +31,8 @@ def _entry_to_numpy(e):
     return out
 
 
-def test_ag_split_shaped_loop(golden_dir):
+@pytest.mark.parametrize("engine", ["fp32", "bf16x3"])
+def test_ag_split_shaped_loop(golden_dir, engine):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import ag_split_bench as ag
@@ -54,10 +55,12 @@ def test_ag_split_shaped_loop(golden_dir):
     model = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=ag.OBJ,
                    enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(dev)
     model.eval()
+    model.gemm_engine = engine            # exact fp32 MFMA, and the opt-in bf16x3 emulation: same checks, same tolerances
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     kw = dict(mode="predcls", AG_object_classes=ag.OBJ, AG_all_predicates=ag.ATT + ag.SPA + ag.CON,
               AG_attention_predicates=ag.ATT, AG_spatial_predicates=ag.SPA, AG_contacting_predicates=ag.CON, iou_threshold=0.5)
     ev_dev, ev_host = SceneGraphEvaluator_HIP(**kw), SceneGraphEvaluator(**kw)
+    ev_host.tie_break = "index"       # exactly equal scores: the device's documented order (numpy's is an accident of its sort)
     ev_dev.register_container(); ev_host.register_container()
 
     rng = np.random.default_rng(2024)

@@ -106,3 +106,31 @@ def test_evaluate_packed_equals_per_clip_calls():
         assert one.result_dict[key] == many.result_dict[key], key
     with pytest.raises(ValueError):
         many.evaluate_packed(gts[:2], packed)
+
+
+def test_tie_break_by_index_only_differs_on_exact_ties():
+    """`tie_break = "index"` (the device evaluator's documented order) gives the reference-pinned results wherever no two
+    candidates of a frame score exactly alike, and a defined result -- lower candidate index first -- where they do"""
+    kw = dict(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON, AG_attention_predicates=ATT,
+              AG_spatial_predicates=SPA, AG_contacting_predicates=CON, iou_threshold=0.5)
+    e = syn.make_entry(31, [4, 3, 5])
+    gt = syn.make_gt_annotation(32, e)
+    rng = np.random.default_rng(1)
+    P = 12
+    pred = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+    pred["attention_distribution"] = rng.standard_normal((P, 3)).astype(np.float32)
+    pred["spatial_distribution"] = rng.random((P, 6)).astype(np.float32)
+    pred["contacting_distribution"] = rng.random((P, 17)).astype(np.float32)
+    a, b = SceneGraphEvaluator(**kw), SceneGraphEvaluator(**kw)
+    b.tie_break = "index"
+    for ev in (a, b):
+        ev.register_container(); ev.evaluate_scene_graph(gt, pred); ev.calculate_mean_recall()
+    assert a.result_dict == b.result_dict                              # distinct random floats: no ties, same answer
+    # saturated probabilities: every spatial / contacting entry exactly 1.0 -> the order is the index order
+    pred["spatial_distribution"][:] = 1.0
+    pred["contacting_distribution"][:] = 1.0
+    c = SceneGraphEvaluator(**kw); c.tie_break = "index"
+    c.register_container(); c.evaluate_scene_graph(gt, pred)
+    c2 = SceneGraphEvaluator(**kw); c2.tie_break = "index"
+    c2.register_container(); c2.evaluate_scene_graph(gt, {k: (v.copy() if hasattr(v, "copy") else v) for k, v in pred.items()})
+    assert c.result_dict == c2.result_dict

@@ -129,7 +129,7 @@ def test_device_recall_identical_to_reference(case, golden_dir):
                                            # more pairs than one pass of the key buffer holds (96 at 26 predicates): chunked
                                            ([97, 3], 20.0), ([300, 150, 7], 25.0), ([193, 192], 0.0), ([500], 15.0)])
 def test_device_hit_table_equals_host(counts, jitter):
-    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container()
+    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container(); host.tie_break = "index"
     dev = _device_eval()
     for c in range(3):                           # several clips pending before one flush
         gt, pred = _clip(70 + c, counts, jitter=jitter, pred_seed=10 + c)
@@ -150,7 +150,7 @@ def test_device_eval_follows_model_output():
     model.eval()
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()},
                           strict=False)
-    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container()
+    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container(); host.tie_break = "index"
     dev = _device_eval()
     for c, counts in enumerate(([4, 2, 5, 3], [6] * 5)):
         e = syn.make_entry(300 + c, counts)
@@ -170,7 +170,7 @@ def test_device_eval_has_no_pairs_per_frame_limit():
     the buffer in chunks whose top-50 lists are merged -- 300 pairs per frame, all three metrics, equal to the host"""
     dev = _device_eval()
     assert dev.max_pairs_per_frame == 96                         # pairs per PASS, no longer a limit
-    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container()
+    host = SceneGraphEvaluator(mode="predcls", **KW); host.register_container(); host.tie_break = "index"
     gt, pred = _clip(5, [300, 300, 97, 96, 1], jitter=20.0, pred_seed=3)
     dev.evaluate_scene_graph(gt, _to_dev(pred))
     host.evaluate_scene_graph(gt, pred)

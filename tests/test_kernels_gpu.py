@@ -317,6 +317,74 @@ def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
     assert e3 <= 2.0 * e1 + 1e-6, (e3, e1)
 
 
+@pytest.mark.parametrize("a_scale,w_scale", [(1e-30, 1e20), (1e20, 1e-30), (1e-20, 1e-10), (1e18, 1e18), (1e-3, 1e3)])
+def test_gemm_bf16x3_operand_ranges(lib, a_scale, w_scale):
+    """the emulation splits x = x1 + x2 + x3 into bf16 planes: x3 = bf16(x - x1 - x2) sits 16 binades below x, so it
+    leaves the bf16 normal range 16 binades before fp32 does.  Operands far from 1 in both directions (products kept
+    inside the fp32 range): the error against fp64, relative to sum |a||b|, stays at the exact engine's level."""
+    M, N, K = 600, 256, 1024
+    g = torch.Generator(device="cuda").manual_seed(int(abs(np.log10(a_scale)) * 7 + abs(np.log10(w_scale))))
+    A = (torch.randn(M + 1, K, device="cuda", generator=g) * a_scale).contiguous()
+    W = (torch.randn(N, K, device="cuda", generator=g) * w_scale).contiguous()
+    C3 = torch.full((M, N), float("nan"), device="cuda")
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    ref = A[:M].double() @ W.double().T
+    mag = (A[:M].double().abs() @ W.double().abs().T)            # sum |a||b| per output: what rounding errors scale with
+    e3 = ((C3.double() - ref).abs() / mag).max().item()
+    e1 = ((C1.double() - ref).abs() / mag).max().item()
+    assert torch.isfinite(C3).all() and torch.isfinite(C1).all()
+    assert e1 < 2e-6 and e3 < 2e-6, (e3, e1)                     # ~ sqrt(K) * 2^-24 for either engine
+    assert e3 <= 4.0 * e1 + 1e-8, (e3, e1)
+
+
+def test_gemm_bf16x3_cancellation(lib):
+    """mixed signs with heavy cancellation: every output is the difference of two nearly equal large sums, so an engine
+    that lost low-order bits of the operands would show it.  a = [u | -u + d], w = [v | v]: a . w = d . v exactly in real
+    arithmetic, |d| ~ 1e-4 |u|"""
+    M, N, K = 520, 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(5)
+    u = torch.randn(M + 1, K // 2, device="cuda", generator=g) * 100.0
+    d = torch.randn(M + 1, K // 2, device="cuda", generator=g) * 0.01
+    A = torch.cat([u, -u + d], dim=1).contiguous()
+    v = torch.randn(N, K // 2, device="cuda", generator=g)
+    W = torch.cat([v, v], dim=1).contiguous()
+    C3 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    ref = A[:M].double() @ W.double().T
+    e3 = (C3.double() - ref).abs().max().item()
+    e1 = (C1.double() - ref).abs().max().item()
+    # both engines round the PRODUCTS' sum in fp32 (|u||v| K ~ 1e5 -> ~1e-2 absolute); neither may be worse than that
+    assert e1 < 0.05 and e3 <= 2.0 * e1 + 1e-3, (e3, e1)
+
+
+def test_gemm_bf16x3_subnormal_tail_is_documented(lib):
+    """where the emulation STOPS being fp32: operands below ~2^-110 have their third plane (and then the second) in the
+    bf16 subnormal range, which the matrix pipe flushes -- the result degrades towards single-bf16 precision while the
+    exact engine (whose products here are still normal fp32 numbers) keeps its accuracy.  Pinned so that a change of
+    this behaviour is noticed; STTran activations are O(1) (LayerNorm outputs), ten binades of headroom are 30x more
+    than they need."""
+    M, N, K = 520, 128, 512
+    g = torch.Generator(device="cuda").manual_seed(6)
+    A = (torch.randn(M + 1, K, device="cuda", generator=g) * 1e-36).contiguous()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 1e30).contiguous()
+    C3 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
+    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    ref = A[:M].double() @ W.double().T
+    mag = A[:M].double().abs() @ W.double().abs().T
+    e3 = ((C3.double() - ref).abs() / mag).max().item()
+    e1 = ((C1.double() - ref).abs() / mag).max().item()
+    assert e1 < 2e-6                                           # the exact engine is unaffected
+    assert e3 < 1e-2                                           # the emulation: still a bf16-grade answer, no NaN / Inf
+    assert torch.isfinite(C3).all()
+
+
 # ---- DSG-DETR on the device: class sequences (lib/dsg_detr.py:545-555) and attention over lengths the host never sees ---
 def _dsg_layout_ref(pair_idx, labels, clip_start, NC):
     """numpy restatement in the reference's own terms: per clip, per class present, the pairs in pair order; position

@@ -291,6 +291,7 @@ def test_sgdet_without_wks_through_both_evaluators():
               AG_spatial_predicates=spa, AG_contacting_predicates=con, iou_threshold=0.5)
     host, dev = SceneGraphEvaluator(**kw), SceneGraphEvaluator_HIP(**kw)
     host.register_container(); dev.register_container()
+    host.tie_break = "index"
     host.evaluate_scene_graph(gt, pred)
     dev.evaluate_scene_graph(gt, pred)
     host.calculate_mean_recall(); dev.calculate_mean_recall()

@@ -43,6 +43,19 @@ def sgdet(weights):
     return _model("sgdet", weights)
 
 
+# Every parity test below that takes `engine` runs twice: on the default exact-fp32 MFMA engine and on the EXPERIMENT
+# bf16x3 emulation forced onto every contraction ("bf16x3_all": small fixtures have fewer than the 512 rows from which
+# the opt-in "bf16x3" mode engages) -- same reference outputs, same tolerance.
+ENGINES = ["fp32", "bf16x3_all"]
+
+
+@pytest.fixture(params=ENGINES)
+def engine(request, predcls, sgdet):
+    predcls.gemm_engine = sgdet.gemm_engine = request.param
+    yield request.param
+    predcls.gemm_engine = sgdet.gemm_engine = "fp32"
+
+
 def _cuda_entry(e):
     return {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) and k != "frame_counts" else v)
             for k, v in e.items()}
@@ -53,7 +66,7 @@ GOLDEN = ["uniform_3x2", "ragged_5", "empty_frames", "two_frames", "uniform_16x1
 
 @pytest.mark.parametrize("name", GOLDEN)
 @pytest.mark.parametrize("hint", [True, False])
-def test_golden_predcls(name, hint, predcls, golden_dir):
+def test_golden_predcls(name, hint, predcls, golden_dir, engine):
     g = np.load(os.path.join(golden_dir, f"sttran_{name}.npz"))
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist())
     ce = _cuda_entry(e)
@@ -71,7 +84,7 @@ def test_golden_predcls(name, hint, predcls, golden_dir):
     predcls.taps = False
 
 
-def test_golden_full_size_64x36(predcls, golden_dir):
+def test_golden_full_size_64x36(predcls, golden_dir, engine):
     """BASELINE.json configs[3] at its full size (2240 pairs, 4410 decoder tokens) against the reference's own
     output on the same seeded clip (the reference CPU forward takes ~5 s; only its [P,26] result is stored)."""
     g = np.load(os.path.join(golden_dir, "sttran_uniform_64x36.npz"))
@@ -83,7 +96,7 @@ def test_golden_full_size_64x36(predcls, golden_dir):
 
 
 @pytest.mark.parametrize("name", ["sgdet_ragged", "sgdet_16x12", "sgdet_empty_frames"])
-def test_golden_sgdet(name, sgdet, golden_dir):
+def test_golden_sgdet(name, sgdet, golden_dir, engine):
     g = np.load(os.path.join(golden_dir, f"sttran_{name}.npz"))
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
     pred = sgdet(_cuda_entry(e))
@@ -94,7 +107,7 @@ def test_golden_sgdet(name, sgdet, golden_dir):
 
 
 @pytest.mark.parametrize("counts", [[4, 7, 1, 9, 2, 2, 6], [1, 1], [0, 3, 0, 2], [35, 20, 35], [5]])
-def test_oracle_fresh_seeds(counts, predcls, weights):
+def test_oracle_fresh_seeds(counts, predcls, weights, engine):
     from oracle import sttran_oracle as orc
     e = syn.make_entry(900 + len(counts), counts, real_masks=True)
     ref = orc.sttran_forward(e, weights, dtype=np.float64)
@@ -104,7 +117,7 @@ def test_oracle_fresh_seeds(counts, predcls, weights):
         np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
 
 
-def test_oracle_many_random_clips(predcls, sgdet, weights):
+def test_oracle_many_random_clips(predcls, sgdet, weights, engine):
     """16 random ragged clips (1..14 frames, 0..9 pairs per frame, empty frames anywhere but last), predcls and
     sgdet alternating, each against the fp64 oracle -- and all of them packed into ONE forward per mode"""
     from oracle import sttran_oracle as orc
@@ -344,7 +357,8 @@ def test_recall_identical_to_reference_pipeline(case, predcls, golden_dir):
 
 @pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_16x12", "dsgdetr_shuffled_boxes",
                                   "dsgdetr_empty_frames"])
-def test_dsg_detr_golden(name, golden_dir):
+@pytest.mark.parametrize("eng", ENGINES)
+def test_dsg_detr_golden(name, golden_dir, eng):
     """Second model on the shared kernels (BASELINE.json configs[4]): lib/dsg_detr.py sgdet branch."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -355,6 +369,7 @@ def test_dsg_detr_golden(name, golden_dir):
     m.eval()
     rep = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     m.taps = True
+    m.gemm_engine = eng
     e = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
     if "box_shuffle_seed" in g.files:      # box rows out of frame order: position indices go by position (dsg_detr.py:551-554)
         e = syn.shuffle_boxes(e, int(g["box_shuffle_seed"]))
@@ -449,7 +464,7 @@ def test_dsg_detr_packed_clips_equal_single_clips():
         np.testing.assert_array_equal(by_ptr[k].cpu().numpy(), packed[k].cpu().numpy(), err_msg=k)
 
 
-def test_longest_action_genome_clip(predcls, weights):
+def test_longest_action_genome_clip(predcls, weights, engine):
     """121 frames (the longest clip of the AG test split) with 0..6 pairs per frame: 120 windows,
     empty frames and empty windows in between"""
     from oracle import sttran_oracle as orc
@@ -464,7 +479,7 @@ def test_longest_action_genome_clip(predcls, weights):
         np.testing.assert_allclose(pred[k].cpu().numpy(), ref[k], atol=TOL, rtol=0, err_msg=k)
 
 
-def test_long_sequences_use_general_attention(predcls, weights):
+def test_long_sequences_use_general_attention(predcls, weights, engine):
     """frames with ~100 pairs: spatial sequences of 100 and temporal windows of 190 tokens go through the
     query-tiled attention kernel (the short-sequence kernel stops at 80 keys); last-layer row pruning
     then needs the general kernel to honour every query row."""

@@ -47,6 +47,7 @@ def main():
                     help="overwrite a 768 MB buffer before every timed launch (operands come from HBM, not from the "
                          "256 MB Infinity Cache a back-to-back replay keeps warm); each launch timed on its own")
     a = ap.parse_args()
+    os.environ["STTRAN_X3_CACHE_PLANES"] = "1"       # --x3: time the GEMM, not the weight split (W stays put here)
     lib = _native.load()
     p = lambda t: C.c_void_p(t.data_ptr())
     torch.zeros(1, device="cuda")
