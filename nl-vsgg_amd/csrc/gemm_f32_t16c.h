@@ -1,0 +1,340 @@
+// gemm_f32_t16c.h -- the two convolutions of the pair fusion on the 16x16x4 kernel structure of gemm_f32_t16.h.
+//
+//   C[ch, n] = W[ch, :] . X[n, :]     ch = 256 output channels (ALL of them in one 256 x 128 tile, so the big operand is
+//                                     fetched once), n = pair * 49 + hw running straight over the pair borders
+//   B_UNION_FLAT  union_func1 (lib/sttran.py:336,386): X[n, k] = union_feat[pair][k][hw], read in place from the NCHW
+//                 tensor -- a thread stages (column, 4 consecutive k) with four dword loads (the lanes of a wave walk 64
+//                 consecutive columns) and ONE ds_write_b128: the transposition happens in the registers;
+//                 V[pair][ch][hw] += acc + bias[ch]: the accumulators START from V, the epilogue is a plain store
+//   B_CONV2       Conv2d(128, 256, 3, padding 1) of the mask branch (lib/sttran.py:342) as an implicit GEMM: K ordered
+//                 (ky, kx, ci) over the channel-last pooled map C2[pair][7][7][128], one tap per four K-steps, a piece =
+//                 4 consecutive channels of one tap = one 16-byte load, taps outside the image are zero pieces;
+//                 V[pair][ch][hw] = BN(ReLU(acc + bias))   (ReLU before BN: lib/sttran.py:342-344)
+//
+// Same machinery as the nn.Linear tile: unpadded 128-byte LDS rows with the 16-byte slot XOR-ed by (row >> 1) & 7
+// (conflict-free ds_read_b128 of 16-row fragments), one ds_read_b128 per four MFMAs, global loads two K-steps ahead in
+// two register sets, one memory instruction per MFMA gap, the last block of a K-step held across the barrier, hybrid
+// data-parallel + stream-K schedule with parked partials and a fix-up launch.  Differences: 8 waves (one workgroup per
+// CU: 96 KB of LDS), the weights sit on the MFMA's "A" port so that a lane holds FOUR CHANNELS of ONE column -- the 16
+// lanes of a group then store 16 consecutive hw of a channel (64 contiguous bytes of V) --, and the per-channel epilogue
+// constants are loaded before the first store (no load waits behind a store that might alias it).
+#pragma once
+#include <type_traits>
+
+#include "gemm_f32_mfma.h"
+
+namespace sttran {
+
+template <int BKIND_>
+struct Tile16C {
+  static constexpr int BM = 256, BN = 128, BKIND = BKIND_;
+  static constexpr int WAVES = BM / 32, NT = WAVES * 64;   // 8 waves, wave w owns channels 32 w .. 32 w + 31
+  static constexpr int NB = BN / 16;
+  static constexpr int STAGE = (BM + BN) * kBK;
+  static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static constexpr int RPR = NT / 8;                       // 64 rows per staging round (8 threads per 128-byte row)
+  static constexpr int AV = BM / RPR;                      // 4 weight pieces per thread and K-step
+  static constexpr int BV = BN * 8 / NT;                   // 2 column pieces
+  static constexpr int GROUP_N = 8;
+  static_assert(BKIND == B_UNION_FLAT || BKIND == B_CONV2, "convolution operand kinds only");
+};
+
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT, 2)
+gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
+               int g_sk, int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB, AV = T::AV, BV = T::BV, RPR = T::RPR;
+  constexpr bool UFLAT = T::BKIND == B_UNION_FLAT;
+  using Geo = ConvGeo<B_CONV2>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  const int frag0 = fr * kBK + ((fg ^ swz) << 2);          // kb = 0; kb = 1 is frag0 ^ 16
+  const int a_base = wave * 32 * kBK;
+  const int srow = tid >> 3, schunk = tid & 7;
+  const int st_a = srow * kBK + ((schunk ^ ((srow >> 1) & 7)) << 2);     // weight piece i: + i * RPR rows
+  // column pieces.  CONV2: (row srow + RPR i, chunk schunk) like the weights.  UNION: thread = (column tid % BN, chunks
+  // 2 (tid / BN) + i): consecutive lanes are consecutive columns = consecutive hw of one channel row in memory
+  const int ucol = tid % BN, uch0 = (tid / BN) * BV;
+  int st_b[BV];
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int r = UFLAT ? ucol : srow + RPR * i, ch = UFLAT ? uch0 + i : schunk;
+    st_b[i] = (BM + r) * kBK + ((ch ^ ((r >> 1) & 7)) << 2);
+  }
+
+  const int G = gridDim.x;
+  const int blk = xcd_remap(blockIdx.x, G);
+  const int tiles_dp = dp_per_wg * G;
+  const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
+
+  int dp_done = 0;
+  for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
+    int tile, ks0, ks1;
+    const bool dp = dp_done < dp_per_wg;
+    if (dp) {
+      tile = dp_done * G + blk;
+      ks0 = 0; ks1 = ksteps;
+      ++dp_done;
+    } else {
+      const int t = it / ksteps;
+      tile = tiles_dp + t;
+      ks0 = it - t * ksteps;
+      ks1 = min(ksteps, ks0 + (rg.end - it));
+    }
+    const int nsteps = ks1 - ks0;
+    int tile_m, tile_n;
+    tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- sources of the staged pieces ---------------------------------------------------------------------------------
+    uint32_t oa[AV];                                           // weights: M = 256 rows exactly, K % 32 == 0 (launcher checks)
+#pragma unroll
+    for (int i = 0; i < AV; ++i) oa[i] = (uint32_t)((((int64_t)(m0 + srow + RPR * i)) * A.ld + schunk * 4 + ks0 * kBK) * 4);
+    const char* const abase = reinterpret_cast<const char*>(A.ptr);
+    const float* pb[BV];                                       // columns: a pointer per piece (the tensors exceed 4 GB)
+    int cy[BV], cx[BV];                                        // CONV2: input row / column of tap (0, 0), -100 = column past N
+    (void)cy; (void)cx;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int n = n0 + (UFLAT ? ucol : srow + RPR * i);
+      const bool v = n < N;
+      const int nn = v ? n : 0, p = nn / kUHW, hw = nn - p * kUHW;
+      if constexpr (UFLAT) {
+        pb[i] = B.ptr + (B.rowoff ? B.rowoff[p] : (int64_t)p * B.ld) + hw + (int64_t)(uch0 + i) * 4 * kUHW;
+      } else {
+        const int oy = hw / Geo::HO, ox = hw - oy * Geo::HO;
+        cy[i] = v ? oy - Geo::PAD : -100; cx[i] = ox - Geo::PAD;
+        pb[i] = B.ptr + (int64_t)p * (Geo::CIN * Geo::HI * Geo::HI) + schunk * 4;
+      }
+    }
+    f32x4 ra[2][AV], rb[2][BV];
+    bool zb[2][BV];                                            // CONV2: the piece is a zero piece (tap outside the image)
+    (void)zb;
+    auto kstep_of = [&](int step) { return ks0 + (step < nsteps ? step : 0); };   // steps past the end re-read step 0 (unused)
+    // load slot n of a K-step: AV weight pieces, then the column pieces (a UNION piece is four dword loads, each its own slot)
+    constexpr int NLS = AV + (UFLAT ? 4 * BV : BV);
+    auto load_slot = [&](int set, int n, int step) {
+      const int ks = kstep_of(step);
+      if (n < AV) {
+        ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)((ks - ks0) * kBK * 4)));
+      } else if constexpr (UFLAT) {
+        const int i = (n - AV) >> 2, e = (n - AV) & 3;
+        rb[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
+      } else {
+        const int i = n - AV;
+        const int k0 = ks * kBK, tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH, ci0 = k0 - tap * Geo::CIN;
+        const int iy = cy[i] + ky, ix = cx[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
+        rb[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
+        zb[set][i] = !ok;
+      }
+    };
+    constexpr int NP = AV + BV;
+    auto store_piece = [&](int set, int n, float* stage) {
+      if (n < AV) *reinterpret_cast<f32x4*>(stage + st_a + n * RPR * kBK) = ra[set][n];
+      else {
+        const int i = n - AV;
+        if constexpr (UFLAT) *reinterpret_cast<f32x4*>(stage + st_b[i]) = rb[set][i];
+        else *reinterpret_cast<f32x4*>(stage + st_b[i]) = zb[set][i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[set][i];
+      }
+    };
+
+    // accumulators: lane (fr, fg) holds, for row block i and column block j, channels 32 w + 16 i + 4 fg + {0..3} of
+    // column n0 + 16 j + fr
+    f32x4 acc[2][NB];
+    const int ch0 = m0 + wave * 32 + 4 * fg;
+    const int colb = n0 + fr;
+    if constexpr (EpiInit<Epi>::value) {
+      if (ks0 == 0) {
+        // C += A B: the K range that starts a tile accumulates onto the output's old values (64 independent loads,
+        // in flight with the first operand loads)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int col = colb + 16 * j;
+              acc[i][j][v] = col < N ? epi.init(ch0 + 16 * i + v, col) : 0.f;
+            }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    constexpr int NBLK = 2 * NB;
+    static_assert(NLS <= NBLK - 1 && NP <= NBLK - 1, "staging slots must fit the blocks of a K-step");
+#pragma unroll
+    for (int n = 0; n < NLS; ++n) load_slot(0, n, 0);
+#pragma unroll
+    for (int n = 0; n < NLS; ++n) load_slot(1, n, 1);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) store_piece(0, n, smem);
+    __syncthreads();
+
+    f32x4 fa[2][2], fb[2];
+    auto read_a = [&](const float* stage, int kb) {
+      const int fo = kb ? (frag0 ^ 16) : frag0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[kb][i] = *reinterpret_cast<const f32x4*>(stage + a_base + i * 16 * kBK + fo);
+    };
+    auto read_b = [&](const float* stage, int sblk) {
+      const int kb = sblk / NB, j = sblk - kb * NB;
+      fb[sblk & 1] = *reinterpret_cast<const f32x4*>(stage + (BM + j * 16) * kBK + (kb ? (frag0 ^ 16) : frag0));
+    };
+    auto mma_block = [&](int sblk) {
+      const int kb = sblk / NB, j = sblk - kb * NB;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kb][i][e], fb[sblk & 1][e], acc[i][j], 0, 0, 0);
+    };
+    read_a(smem, 0);
+    read_b(smem, 0);
+    auto k_step = [&](int t, auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const float* cur = smem + set * T::STAGE;
+      float* nxt = smem + (set ^ 1) * T::STAGE;
+#pragma unroll
+      for (int sb = 0; sb < NBLK; ++sb) {
+        if (sb + 1 < NBLK) read_b(cur, sb + 1);
+        if (sb == NB - 3) read_a(cur, 1);
+        if (sb < NLS) load_slot(set, sb, t + 2);
+        if (sb >= NBLK - NP) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
+        if (sb + 1 < NBLK) {
+          mma_block(sb);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb < NLS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (sb >= NBLK - NP) {
+            if constexpr (!UFLAT) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      read_a(nxt, 0);
+      read_b(nxt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_block(NBLK - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      int t = 0;
+      for (; t + 1 < nsteps; t += 2) {
+        k_step(t, std::integral_constant<int, 0>{});
+        k_step(t + 1, std::integral_constant<int, 1>{});
+      }
+      if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
+    }
+
+    if (nsteps == ksteps) {
+      // whole tile: per-channel constants first (8 channels per lane), then only stores
+      typename Epi::Consts cst[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cst[i][v] = epi.consts(ch0 + 16 * i + v);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int col = colb + 16 * j;
+        if (col < N) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) epi.store(ch0 + 16 * i + v, col, acc[i][j][v], cst[i][v]);
+        }
+      }
+    } else {
+      f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sp[(i * NB + j) * NT] = acc[i][j];
+    }
+    if (!dp) it += nsteps;
+  }
+}
+
+// grid = (stream-K tiles, 2 * NB): sums the parked partial accumulators of a split tile in ascending workgroup order
+template <class T, class Epi>
+__global__ void __launch_bounds__(T::NT)
+gemm16c_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
+                     const float* __restrict__ slab, Epi epi) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB;
+  const int tile = blockIdx.x;
+  const int t0 = tile * ksteps, t1 = t0 + ksteps;
+  const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t1 - 1, sk_base, sk_rem);
+  if (b_lo == b_hi) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int ij = blockIdx.y, i = ij / NB, j = ij % NB;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* base = reinterpret_cast<const f32x4*>(slab) + (int64_t)ij * NT + tid;
+  for (int b = b_lo; b <= b_hi; b += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int bb = b + u;
+      const bool ok = bb <= b_hi;
+      const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
+      const f32x4* sp = base + ((int64_t)(ok ? bb : b_lo) * 2 + slot) * (BM * BN / 4);
+      v[u] = ok ? *sp : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  const int gt = tiles_dp + tile;
+  int tile_m, tile_n;
+  tile_origin<T::GROUP_N>(gt, tiles_m, tiles_n, tile_m, tile_n);
+  const int ch = tile_m * BM + wave * 32 + 16 * i + 4 * fg;
+  const int col = tile_n * BN + 16 * j + fr;
+  if (col < N) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) epi.store(ch + v, col, acc[v], epi.consts(ch + v));
+  }
+}
+
+// ---- epilogues: row = output channel, col = pair * 49 + hw ----------------------------------------------------------
+// union_func1: the partial sums START from V (EpiInit), so the tile's epilogue -- or the fix-up's -- adds the bias and stores
+struct EpiUnionT16 {
+  float* V; const float* bias; int C;
+  static constexpr bool kInit = true;
+  struct Consts { float b; };
+  __device__ __forceinline__ float* at(int row, int col) const {
+    const int p = col / kUHW, hw = col - p * kUHW;
+    return V + ((int64_t)p * C + row) * kUHW + hw;
+  }
+  __device__ __forceinline__ float init(int row, int col) const { return *at(row, col); }
+  __device__ __forceinline__ Consts consts(int row) const { return Consts{bias[row]}; }
+  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const { *at(row, col) = v + c.b; }
+};
+// conv3x3: ReLU, then eval-mode BatchNorm (lib/sttran.py:342-344), channel-major into V[p][c][hw]
+struct EpiConvT16 {
+  float* V; const float* bias; const float* scale; const float* shift; int C;
+  struct Consts { float b, s, t; };
+  __device__ __forceinline__ Consts consts(int row) const { return Consts{bias[row], scale[row], shift[row]}; }
+  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const {
+    const int p = col / kUHW, hw = col - p * kUHW;
+    V[((int64_t)p * C + row) * kUHW + hw] = relu_nan(v + c.b) * c.s + c.t;
+  }
+};
+
+}  // namespace sttran

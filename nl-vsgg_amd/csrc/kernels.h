@@ -49,6 +49,12 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
 hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, const EpiConvRelBn& epi, int P,
                              float* slab);
 
+// the same two convolutions on the 16x16x4 kernel structure (gemm_f32_t16c.h): the product path since round 3
+hipError_t launch_union_conv_t16(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
+                                 int P, int K, float* slab);
+hipError_t launch_mask_conv2_t16(hipStream_t s, const float* w4, const float* c2, const float* bias, const float* scale,
+                                 const float* shift, float* V, int P, float* slab);
+
 hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks);
 
 // bf16x3 fp32 emulation (gemm_bf16x3.h; experiment): weight planes [3][rows][ldp] bf16 made by split_planes

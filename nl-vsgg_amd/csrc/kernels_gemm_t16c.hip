@@ -1,0 +1,53 @@
+// kernels_gemm_t16c.hip -- union 1x1 conv and conv3x3 on the 16x16x4 kernel structure (gemm_f32_t16c.h): launchers
+#include "gemm_f32_t16c.h"
+#include "gemm_launch.h"
+
+namespace sttran {
+
+template <class T, class Epi>
+static hipError_t launch_t16c(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K, float* slab,
+                              const Epi& epi) {
+  static DeviceMarks marks;
+  auto kern = gemm16c_kernel<T, Epi>;
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  if (M != T::BM || K % kBK != 0 || N <= 0) return hipErrorInvalidValue;
+  const int tm = 1, tn = (N + T::BN - 1) / T::BN, tiles = tm * tn;
+  const int ksteps = K / kBK;
+  const SkPlan sp = sk_plan(TILE_256x128, tiles, ksteps);            // one workgroup per CU (96 KB of LDS), 256 x 128 park slots
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
+  bool split = false;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
+                     base, rem, slab, epi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !split) return e;
+  hipLaunchKernelGGL((gemm16c_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps,
+                     sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, epi);
+  return hipGetLastError();
+}
+
+// union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]  (u_off optional: pair p's block starts at U + u_off[p] floats)
+hipError_t launch_union_conv_t16(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
+                                 int P, int K, float* slab) {
+  if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
+  GemmOperand A{W, (int64_t)K, nullptr, 0, nullptr};
+  GemmOperand B{U, (int64_t)K * kUHW, nullptr, P, u_off};
+  return launch_t16c<Tile16C<B_UNION_FLAT>, EpiUnionT16>(s, A, B, 256, P * kUHW, K, slab, EpiUnionT16{V, bias, 256});
+}
+
+// Conv2d(128,256,k3,p1) -> ReLU -> BN: w4 = conv.4.weight in (ky, kx, ci) K order [256][1152], c2 channel-last [P][7][7][128]
+hipError_t launch_mask_conv2_t16(hipStream_t s, const float* w4, const float* c2, const float* bias, const float* scale,
+                                 const float* shift, float* V, int P, float* slab) {
+  if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
+  GemmOperand A{w4, 1152, nullptr, 0, nullptr};
+  GemmOperand B{c2, 0, nullptr, 0, nullptr};
+  return launch_t16c<Tile16C<B_CONV2>, EpiConvT16>(s, A, B, 256, P * kUHW, 1152, slab, EpiConvT16{V, bias, scale, shift, 256});
+}
+
+}  // namespace sttran

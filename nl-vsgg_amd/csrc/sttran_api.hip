@@ -1061,6 +1061,9 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                        epi_plain(X0, LD, W(h, "subj_fc.bias"))))) return rc;
   if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off + P}, W(h, "obj_fc.weight"), (int)P, 512, FD,
                        epi_plain(X0 + 512, LD, W(h, "obj_fc.bias"))))) return rc;
+  // the two convolutions on the 16x16x4 kernel structure (gemm_f32_t16c.h); STTRAN_CONV_ENGINE=32x32 keeps round 2's
+  // gemm_sk_kernel<B_UNION_FLAT / B_CONV2> for A/B runs
+  static const bool conv_t16 = !(getenv("STTRAN_CONV_ENGINE") && std::string(getenv("STTRAN_CONV_ENGINE")) == "32x32");
   {
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
     {
@@ -1075,10 +1078,13 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
                  x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_CONV2>,EpiConvRows>"
-                    : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
+                    : conv_t16 ? "gemm16c_kernel<Tile16C<B_CONV2>,EpiConvT16>"
+                               : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
     if (x3)
       HIPCK(launch_mask_conv2_x3(s, h->w4_planes, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
                                  h->slab.as<float>()));
+    else if (conv_t16)
+      HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->slab.as<float>()));
     else
       HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
   }
@@ -1088,10 +1094,14 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
                  x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_UNION_FLAT>,EpiUnionRows>"
-                    : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
+                    : conv_t16 ? "gemm16c_kernel<Tile16C<B_UNION_FLAT>,EpiUnionT16>"
+                               : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
     if (x3)
       HIPCK(launch_union_conv_x3(s, union_base, union_off, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD,
                                  h->slab.as<float>()));
+    else if (conv_t16)
+      HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+                                  h->slab.as<float>()));
     else
       HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                               h->slab.as<float>()));

@@ -41,3 +41,27 @@ def test_bench_accepts_the_driver_flags():
     assert "launch_ranks(args.gpus" in src and "os.exec" not in src     # --gpus N without a launcher: fresh children, never exec
     assert src.count("env.barrier(gatherer)") >= 2                      # both sides of the timed region
     assert "PredictionGatherer" in src                                  # the tested gather is the timed gather
+
+
+def test_newest_driver_bench_line_has_the_contract_fields():
+    """the DRIVER's own record of the last round (BENCH_rNN.json at the repo root: `parsed` = the line it read from
+    bench.py on a fresh MI355X): the same contract checks as for the committed profile line"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))
+    if not files:
+        import pytest
+        pytest.skip("no driver bench record in this checkout")
+    rec = json.load(open(files[-1]))
+    d = rec.get("parsed") or {}
+    assert rec.get("rc", 0) == 0 and d, files[-1]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, (files[-1], k)
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0
+    # value = whole-job frames / time of the timed steps
+    per_step = d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] * d["n_gpus"]
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

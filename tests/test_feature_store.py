@@ -60,6 +60,28 @@ def test_loader_async_upload(tmp_path):
         np.testing.assert_array_equal(got, np.concatenate([r[3] for r in ref]))
 
 
+@pytest.mark.gpu
+def test_loader_async_upload_of_the_reference_layout_fixture(golden_dir):
+    """f-4's GPU leg on the COMMITTED fixture (files in the reference writer's layout, incl. the frame without
+    detections): pinned staging + one asynchronous upload per clip on the side stream, slots reused, bytes on the device
+    equal the stored ones"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root, exp, frames = _fixture(golden_dir)
+    dirs = [os.path.join(root, f) for f in frames]
+    n = [len(exp[f"class_{t}"]) for t in range(len(frames))]
+    cat = lambda k: np.concatenate([exp[f"{k}_{t}"] for t in range(len(frames))])
+    ld = ClipFeatureLoader(device="cuda:0")
+    for rep in range(4):                                 # both slots, reused
+        rec = ld.load(dirs)
+        assert rec["features"].is_cuda and rec["boxes"].is_cuda and rec["boxes_per_frame"] == n
+        torch.cuda.current_stream().wait_event(rec["ready"])
+        assert rec["features"].cpu().numpy().tobytes() == cat("feat").tobytes()
+        assert rec["boxes"][:, 1:].cpu().numpy().tobytes() == cat("rect").tobytes()
+        np.testing.assert_array_equal(rec["boxes"][:, 0].cpu().numpy(), np.repeat(np.arange(len(frames)), n).astype(np.float32))
+        np.testing.assert_array_equal(rec["classes"].numpy(), cat("class"))
+
+
 def _fixture(golden_dir):
     root = os.path.join(golden_dir, "frame_features")
     exp = np.load(os.path.join(root, "expected.npz"))

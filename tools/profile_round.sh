@@ -1,35 +1,60 @@
-set -x
+#!/bin/bash
+# Profiles of one round, taken on the GPU box at the commit the snapshot was made from:
+#     gpurun -- bash tools/profile_round.sh r3_f $(git rev-parse --short HEAD)
+# (the box has no .git: the commit is an argument, and it is stamped into every JSON this script derives).
+# Every rocprofv3 pass is `--kernel-trace` with at most ONE `--pmc` counter (the pool refuses other combinations) and
+# has python3 directly behind `--`.  Outputs go to gpurun_out/<prefix>_*; copy the summaries to profiles/.
+set -euo pipefail
+P=${1:?prefix, e.g. r3_f}
+C=${2:?commit the library was built from}
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-C=538c50d
-# 1. kernel traces (per-step averages: --profile-only-batch)
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+kt() {   # kt <name> <bench args...>: kernel trace + stats of one --profile-only-batch run -> <name>_kernel_stats.csv
+  local name=$1; shift
+  rm -rf "$O/${P}_kt_$name"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${P}_kt_$name" -- python3 bench.py "$@" --profile-only-batch \
+    > "$O/${P}_kt_$name.json" 2> "$O/${P}_kt_$name.err"
+  cp "$O/${P}_kt_$name"/*/*kernel_stats.csv "$O/${P}_${name}_kernel_stats.csv"
+}
+pmc() {  # pmc <dir name> <counter> <bench args...>
+  local name=$1 ctr=$2; shift 2
+  rm -rf "$O/${P}_pmc_${name}_$ctr"
+  rocprofv3 --pmc "$ctr" --kernel-trace --output-format csv -d "$O/${P}_pmc_${name}_$ctr" -- python3 bench.py "$@" --profile-only-batch \
+    > /dev/null 2> "$O/${P}_pmc_${name}_$ctr.err"
+}
+# 1. kernel traces: per-step averages of the three workloads of the line, the single clip, the second model
+kt 16x12 --workload 16x12 --steps 20 --warmup 3
+kt 64x36 --workload 64x36 --steps 10 --warmup 3
+kt single --clips-per-step 1 --steps 50 --warmup 3
+kt single_64x36 --workload 64x36 --clips-per-step 1 --steps 20 --warmup 3
+kt dsgdetr_16x12 --model dsgdetr --steps 10 --warmup 3
+kt dsgdetr_64x36 --model dsgdetr --workload 64x36 --steps 10 --warmup 3
+# 2. fabric traffic of the GEMM class (FETCH_SIZE x 2 per the gfx950 note, WRITE_SIZE), STTran and DSG-DETR
 for w in 16x12 64x36; do
-  st=20; [ $w = 64x36 ] && st=10
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2e_kt_$w -- python3 bench.py --workload $w --steps $st --warmup 3 --profile-only-batch > gpurun_out/r2e_kt_$w.json 2> gpurun_out/r2e_kt_$w.err
-done
-# 2. single clip trace
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2e_kt_single -- python3 bench.py --clips-per-step 1 --steps 50 --warmup 3 --profile-only-batch > gpurun_out/r2e_kt_single.json 2> gpurun_out/r2e_kt_single.err
-# 3. PMC traffic passes (separate passes, kernel-trace only)
-for w in 16x12 64x36; do
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/r2e_pmc_${w}_$c -- python3 bench.py --workload $w --steps 3 --warmup 1 --profile-only-batch > /dev/null 2> gpurun_out/r2e_pmc_${w}_$c.err
-  done
+  for c in FETCH_SIZE WRITE_SIZE; do pmc "$w" $c --workload $w --steps 3 --warmup 1; done
   cps=64; [ $w = 64x36 ] && cps=4
-  python3 tools/pmc_traffic.py gpurun_out/r2e_pmc_${w}_FETCH_SIZE gpurun_out/r2e_pmc_${w}_WRITE_SIZE $C $cps > gpurun_out/r2e_pmc_traffic_$w.json
+  python3 tools/pmc_traffic.py "$O/${P}_pmc_${w}_FETCH_SIZE" "$O/${P}_pmc_${w}_WRITE_SIZE" "$C" $cps > "$O/${P}_pmc_traffic_$w.json"
 done
-# 4. MFMA busy passes
-for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/r2e_pmcm_$c -- python3 bench.py --steps 3 --warmup 1 --profile-only-batch > /dev/null 2> gpurun_out/r2e_pmcm_$c.err
+for c in FETCH_SIZE WRITE_SIZE; do pmc dsg $c --model dsgdetr --steps 3 --warmup 1; done
+python3 tools/pmc_traffic.py "$O/${P}_pmc_dsg_FETCH_SIZE" "$O/${P}_pmc_dsg_WRITE_SIZE" "$C" 64 > "$O/${P}_pmc_traffic_dsgdetr_16x12.json"
+# 3. MFMA-pipe occupancy of the dominant kernels (one counter per pass)
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do pmc busy $c --steps 3 --warmup 1; done
+for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "GemmTile<256, 128, 4, 2, 4>" "GemmTile<256, 128, 4, 2, 2>"; do
+  tag=$(echo "$k" | tr -c 'A-Za-z0-9' '_' | cut -c1-40)
+  python3 tools/pmc_mfma_busy.py "$O/${P}_pmc_busy_" "$k" "$C" > "$O/${P}_pmc_mfma_busy_$tag.json"
 done
-python3 tools/pmc_mfma_busy.py gpurun_out/r2e_pmcm_ "GemmTile<256, 128, 4, 2, 3>, sttran::EpiLinearV" $C > gpurun_out/r2e_pmc_mfma_busy.json
-# 5. bench lines (unprofiled)
-python3 bench.py > gpurun_out/r2e_bench_default_with_cpu.json 2> gpurun_out/r2e_bench_default.err
-python3 bench.py --workload 64x36 --steps 20 --no-cpu-baseline --no-extra-workloads > gpurun_out/r2e_bench_64x36.json 2>/dev/null
-python3 bench.py --workload 64x36 --clips-per-step 1 --steps 20 --no-cpu-baseline --no-extra-workloads > gpurun_out/r2e_bench_64x36_single_clip.json 2>/dev/null
-python3 bench.py --clips-per-step 1 --no-cpu-baseline --no-extra-workloads > gpurun_out/r2e_bench_16x12_single_clip.json 2>/dev/null
-python3 bench.py --clips-per-step 16 --no-cpu-baseline --no-extra-workloads > gpurun_out/r2e_bench_16x12_16clips.json 2>/dev/null
-python3 bench.py --model dsgdetr --no-cpu-baseline > gpurun_out/r2e_bench_dsgdetr_16x12.json 2>/dev/null
-python3 bench.py --model dsgdetr --workload 64x36 --steps 10 --no-cpu-baseline > gpurun_out/r2e_bench_dsgdetr_64x36.json 2>/dev/null
-python3 tools/ag_split_bench.py > gpurun_out/r2e_ag_split_shaped.json 2>/dev/null
-ls gpurun_out/r2e_kt_16x12/*/ | head; find gpurun_out -name "*kernel_stats.csv" | head
-du -sh gpurun_out
+# 4. bench lines (unprofiled)
+python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
+python3 bench.py --workload 64x36 --steps 20 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_64x36.json" 2>/dev/null
+python3 bench.py --workload 64x36 --clips-per-step 1 --steps 20 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_64x36_single_clip.json" 2>/dev/null
+python3 bench.py --clips-per-step 1 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_16x12_single_clip.json" 2>/dev/null
+python3 bench.py --clips-per-step 16 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_16x12_16clips.json" 2>/dev/null
+python3 bench.py --model dsgdetr --no-cpu-baseline > "$O/${P}_bench_dsgdetr_16x12.json" 2>/dev/null
+python3 bench.py --model dsgdetr --workload 64x36 --steps 10 --no-cpu-baseline > "$O/${P}_bench_dsgdetr_64x36.json" 2>/dev/null
+python3 tools/ag_split_bench.py > "$O/${P}_ag_split_shaped.json" 2>/dev/null
+# two ranks on this one GPU over gloo (the N > 1 code path, self-launched): what the 8-GPU driver run will execute
+BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline \
+  > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
+ls "$O" | grep "^${P}_" | grep -v "_kt_\|_pmc_[a-z0-9]*_[A-Z]" | head -60
+du -sh "$O"
