@@ -186,72 +186,75 @@ struct EpiLinearV {
 // turns a tile's epilogue into a chain of NV dependent memory round trips per row (~0.5 us each: ~20 us per 128 x 176
 // tile, measured as 4.4 K-steps of 61).  Same operation order as put4 (bit-identical results).
 // cols[j] = first column of group j (col % 4 == 0); no per-column affine here (launchers route those to vec()).
-template <int NV>
-__device__ __forceinline__ void epi_linear_strip(const EpiLinear& e, int row, const int (&cols)[NV], const f32x4 (&acc)[NV]) {
-  // every condition below is wave-uniform (a property of the launch) except the validity of the two output rows, and
+// HRB / H2 / HRS (compile time) = per-slot position bias / second output row / residual present: the launch-uniform
+// flags of EpiLinear as template parameters, so that the registers of an absent operand are never allocated
+template <int NV, bool HRB, bool H2, bool HRS>
+__device__ __forceinline__ void epi_linear_strip_t(const EpiLinear& e, int row, const int (&cols)[NV], const f32x4 (&acc)[NV]) {
   // loads never sit under a divergent condition: a disabled output row reads row 0 / slot 0 and is masked at the store
-  const bool hb = e.bias != nullptr, hrb = e.rowbias != nullptr, hrs = e.res != nullptr, h2 = e.out_rowidx2 != nullptr;
   const int o1 = e.out_rowidx ? e.out_rowidx[row] : row;
-  const int o2 = h2 ? e.out_rowidx2[row] : -1;
-  const float* rb1 = hrb ? e.rowbias + (int)e.rowslot[o1 >= 0 ? o1 : 0] * e.rb_ld : nullptr;
-  const float* rb2 = (hrb && h2) ? e.rowbias + (int)e.rowslot[o2 >= 0 ? o2 : 0] * e.rb_ld : nullptr;
-  const float* rs = hrs ? e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[row] : row) * e.ldres : nullptr;
+  const int o2 = H2 ? e.out_rowidx2[row] : -1;
+  const float* rb1 = HRB ? e.rowbias + (int)e.rowslot[o1 >= 0 ? o1 : 0] * e.rb_ld : nullptr;
+  const float* rb2 = (HRB && H2) ? e.rowbias + (int)e.rowslot[o2 >= 0 ? o2 : 0] * e.rb_ld : nullptr;
+  const float* rs = HRS ? e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[row] : row) * e.ldres : nullptr;
   const int rbmax = e.rb_cols - 4;                 // columns past rb_cols read (and discard) the last valid group
-  f32x4 b[NV], r1[NV], r2[NV], rr[NV];
+  const bool hb = e.bias != nullptr;
+  f32x4 v[NV], r1[HRB ? NV : 1], r2[(HRB && H2) ? NV : 1], rr[HRS ? NV : 1];
   if (hb) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) b[j] = *reinterpret_cast<const f32x4*>(e.bias + cols[j]);
+    for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(e.bias + cols[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (hrb) {
+  if constexpr (HRB) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) r1[j] = *reinterpret_cast<const f32x4*>(rb1 + min(cols[j], rbmax));
-  }
-  if (hrb && h2) {
+    if constexpr (H2) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) r2[j] = *reinterpret_cast<const f32x4*>(rb2 + min(cols[j], rbmax));
+      for (int j = 0; j < NV; ++j) r2[j] = *reinterpret_cast<const f32x4*>(rb2 + min(cols[j], rbmax));
+    }
   }
-  if (hrs) {
+  if constexpr (HRS) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) rr[j] = *reinterpret_cast<const f32x4*>(rs + cols[j]);
   }
-  f32x4 v0[NV];
+  // v = acc + bias (an absent bias adds +0: x + 0 == x for every x the epilogue can see, -0 included as -0 + 0 = +0 only
+  // for an exact -0 accumulator, which compares equal)
 #pragma unroll
-  for (int j = 0; j < NV; ++j) v0[j] = acc[j];
-  if (hb) {
+  for (int j = 0; j < NV; ++j) v[j] = hb ? acc[j] + v[j] : acc[j];
+  auto finish = [&](int orow, const f32x4* rbv) {
+    if (orow < 0) return;
+    float* dst = e.C + (int64_t)orow * e.ldc;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v0[j] += b[j];
-  }
-  auto finish = [&](int orow, const f32x4 (&rbv)[NV]) {
-    f32x4 v[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = v0[j];
-    if (hrb) {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const f32x4 w = v[j] + rbv[j];
+    for (int j = 0; j < NV; ++j) {
+      f32x4 w = v[j];
+      if constexpr (HRB) {
+        const f32x4 w2 = w + rbv[j];
         const bool in = cols[j] < e.rb_cols;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[j][c] = in ? w[c] : v[j][c];
+        for (int c = 0; c < 4; ++c) w[c] = in ? w2[c] : w[c];
       }
-    }
-    if (e.relu) {
+      if (e.relu) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[j][c] = relu_nan(v[j][c]);
-    }
-    if (hrs) {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) v[j] += rr[j];
-    }
-    if (orow >= 0) {
-      float* dst = e.C + (int64_t)orow * e.ldc;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4*>(dst + cols[j]) = v[j];
+        for (int c = 0; c < 4; ++c) w[c] = relu_nan(w[c]);
+      }
+      if constexpr (HRS) w += rr[j];
+      *reinterpret_cast<f32x4*>(dst + cols[j]) = w;
     }
   };
   finish(o1, r1);
-  if (h2) finish(o2, r2);
+  if constexpr (H2) finish(o2, r2);
+}
+
+template <int NV>
+__device__ __forceinline__ void epi_linear_strip(const EpiLinear& e, int row, const int (&cols)[NV], const f32x4 (&acc)[NV]) {
+  const bool hrb = e.rowbias != nullptr, h2 = e.out_rowidx2 != nullptr, hrs = e.res != nullptr;   // launch-uniform
+  if (!hrb && !hrs) epi_linear_strip_t<NV, false, false, false>(e, row, cols, acc);
+  else if (!hrb) epi_linear_strip_t<NV, false, false, true>(e, row, cols, acc);
+  else if (!h2 && !hrs) epi_linear_strip_t<NV, true, false, false>(e, row, cols, acc);
+  else if (h2 && !hrs) epi_linear_strip_t<NV, true, true, false>(e, row, cols, acc);
+  else if (!h2) epi_linear_strip_t<NV, true, false, true>(e, row, cols, acc);
+  else epi_linear_strip_t<NV, true, true, true>(e, row, cols, acc);
 }
 
 // element-wise functors (heads, unaligned outputs) get a vec() that falls back to four scalar calls

@@ -253,24 +253,40 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
     const int row0 = m0 + wave * 32 + fr;
     const int col0 = n0 + 4 * fg;
     if (nsteps == ksteps) {
-      // a row's strip in two halves (register budget): all loads of a half are issued before its stores
-      constexpr int H0 = (NB + 1) / 2, H1 = NB - H0;
-      int c0[H0], c1[H1 > 0 ? H1 : 1];
+      // One strip per output row: ALL of the row's loads (bias, position bias, residual) are issued before its first
+      // store.  vmcnt counts stores too on gfx9 and memory operations retire in order, so a load issued behind stores
+      // waits for their acknowledgement: every load -> store phase costs a load latency plus a store round trip.  The
+      // 176-column tile has no registers for a whole row's operands next to its 88 accumulator registers (it spills):
+      // its rows go in two halves (measured: 140.2 vs 138.2 TFLOP/s on [21120,1936,1936] + residual; the 128-column
+      // tile gains 1 % from whole rows)
+      if constexpr (NB <= 8) {
+        int cols[NB];
 #pragma unroll
-      for (int j = 0; j < H0; ++j) c0[j] = col0 + 16 * j;
+        for (int j = 0; j < NB; ++j) cols[j] = col0 + 16 * j;
 #pragma unroll
-      for (int j = 0; j < H1; ++j) c1[j] = col0 + 16 * (H0 + j);
+        for (int i = 0; i < 2; ++i) {
+          const int r = row0 + 16 * i;
+          if (r < M) epi_linear_strip<NB>(epi.e, r, cols, acc[i]);
+        }
+      } else {
+        constexpr int H0 = (NB + 1) / 2, H1 = NB - H0;
+        int c0[H0], c1[H1];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = row0 + 16 * i;
-        if (r < M) {
-          f32x4 a0[H0], a1[H1 > 0 ? H1 : 1];
+        for (int j = 0; j < H0; ++j) c0[j] = col0 + 16 * j;
 #pragma unroll
-          for (int j = 0; j < H0; ++j) a0[j] = acc[i][j];
+        for (int j = 0; j < H1; ++j) c1[j] = col0 + 16 * (H0 + j);
 #pragma unroll
-          for (int j = 0; j < H1; ++j) a1[j] = acc[i][H0 + j];
-          epi_linear_strip<H0>(epi.e, r, c0, a0);
-          if constexpr (H1 > 0) epi_linear_strip<H1>(epi.e, r, c1, a1);
+        for (int i = 0; i < 2; ++i) {
+          const int r = row0 + 16 * i;
+          if (r < M) {
+            f32x4 a0[H0], a1[H1];
+#pragma unroll
+            for (int j = 0; j < H0; ++j) a0[j] = acc[i][j];
+#pragma unroll
+            for (int j = 0; j < H1; ++j) a1[j] = acc[i][H0 + j];
+            epi_linear_strip<H0>(epi.e, r, c0, a0);
+            epi_linear_strip<H1>(epi.e, r, c1, a1);
+          }
         }
       }
     } else {
