@@ -3,7 +3,11 @@
  * (INTEGRATION.md section 2), and tests/test_c_host_gpu.py uses it to show that the C ABI alone reproduces
  * the Python shim's outputs bit for bit.
  *
- *   sttran_c_host <weights.bin> <entry.bin> <out.bin>
+ *   sttran_c_host <weights.bin> <entry.bin> <out.bin> [<out2.bin>]
+ *
+ * With <out2.bin> the program also forwards a BATCH of two clips handed over as per-clip pointer tables (SttranInputs
+ * form 2: nothing concatenated, every clip's pair_idx local to the clip) -- here the same clip twice, which is the
+ * cheapest way to own two clips -- and writes the 2 P rows of that call.
  *
  * weights.bin : int32 n, then n x { int32 keylen, key bytes, int32 ndim, int64 shape[ndim], float data[] }
  * entry.bin   : int32 mode, int64 B, int64 P, int32 T, int32 frame_counts[T], float features[B*2048],
@@ -52,8 +56,8 @@ static void* to_device(const void* src, size_t bytes) {
 
 int main(int argc, char** argv) {
   SttranHandle* h = NULL;
-  if (argc != 4) {
-    fprintf(stderr, "usage: %s weights.bin entry.bin out.bin\n", argv[0]);
+  if (argc != 4 && argc != 5) {
+    fprintf(stderr, "usage: %s weights.bin entry.bin out.bin [out2.bin]\n", argv[0]);
     return 2;
   }
   FILE* fe = fopen(argv[2], "rb");
@@ -141,6 +145,52 @@ int main(int argc, char** argv) {
   }
   fclose(fo);
   printf("%s: P=%lld pairs, T=%d frames -> %s\n", sttran_version(), (long long)P, T, argv[3]);
+
+  if (argc == 5) {
+    /* ---- two clips in one call, by pointer: tables of device pointers, per-clip sizes, frame counts of both clips ---- */
+    const float* t_feat[2] = {(const float*)dev[0], (const float*)dev[0]};
+    const int64_t* t_pair[2] = {(const int64_t*)dev[1], (const int64_t*)dev[1]};
+    const int64_t* t_lab[2] = {(const int64_t*)dev[2], (const int64_t*)dev[2]};
+    const float* t_uni[2] = {(const float*)dev[3], (const float*)dev[3]};
+    const float* t_mask[2] = {(const float*)dev[4], (const float*)dev[4]};
+    const int64_t nbx[2] = {B, B}, npr[2] = {P, P};
+    const int32_t clipf[2] = {T, T};
+    int32_t* counts2 = (int32_t*)malloc(8 * (size_t)T + 4);
+    if (!counts2) return 1;
+    memcpy(counts2, counts, 4 * (size_t)T);
+    memcpy(counts2 + T, counts, 4 * (size_t)T);
+    float *att2 = NULL, *spa2 = NULL, *con2 = NULL;
+    HIPCHECK(hipMalloc((void**)&att2, (size_t)P * 2 * 3 * 4));
+    HIPCHECK(hipMalloc((void**)&spa2, (size_t)P * 2 * 6 * 4));
+    HIPCHECK(hipMalloc((void**)&con2, (size_t)P * 2 * 17 * 4));
+    SttranInputs in2;
+    memset(&in2, 0, sizeof in2);
+    in2.struct_size = sizeof in2;
+    in2.num_clips = 2; in2.num_boxes = 2 * B; in2.num_pairs = 2 * P; in2.num_frames = 2 * T; in2.im_idx_dtype = STTRAN_DTYPE_F32;
+    in2.clip_num_frames = clipf; in2.frame_counts = counts2;
+    in2.clip_features = t_feat; in2.clip_pair_idx = t_pair; in2.clip_labels = t_lab; in2.clip_union_feat = t_uni;
+    in2.clip_spatial_masks = t_mask; in2.clip_num_boxes = nbx; in2.clip_num_pairs = npr;
+    SttranOutputs out2;
+    memset(&out2, 0, sizeof out2);
+    out2.struct_size = sizeof out2;
+    out2.attention_distribution = att2; out2.spatial_distribution = spa2; out2.contacting_distribution = con2;
+    CHECK(sttran_forward(h, &in2, &out2, stream));
+    CHECK(sttran_sync_check(h, stream));
+    FILE* f2 = fopen(argv[4], "wb");
+    if (!f2) { perror(argv[4]); return 1; }
+    float* d2[3] = {att2, spa2, con2};
+    for (int i = 0; i < 3; ++i) {
+      float* host = (float*)malloc(no[i] * 8 + 4);
+      if (!host) return 1;
+      HIPCHECK(hipMemcpy(host, d2[i], no[i] * 8, hipMemcpyDeviceToHost));
+      fwrite(host, 4, no[i] * 2, f2);
+      free(host);
+    }
+    fclose(f2);
+    printf("two clips by pointer: %lld pairs -> %s\n", (long long)(2 * P), argv[4]);
+    hipFree(att2); hipFree(spa2); hipFree(con2);
+    free(counts2);
+  }
 
   sttran_destroy(h);
   for (int i = 0; i < 6; ++i) hipFree(dev[i]);

@@ -61,7 +61,8 @@ def test_c_host_matches_python_shim(tmp_path):
         for k, dt in (("features", np.float32), ("pair_idx", np.int64), ("labels", np.int64), ("union_feat", np.float32),
                       ("spatial_masks", np.float32), ("im_idx", np.float32)):
             f.write(np.ascontiguousarray(e[k], dtype=dt).tobytes())
-    r = subprocess.run([exe, wpath, epath, opath], capture_output=True, text=True, timeout=300)
+    o2path = str(tmp_path / "out2.bin")
+    r = subprocess.run([exe, wpath, epath, opath, o2path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     got = np.fromfile(opath, dtype=np.float32)
     assert got.size == P * 26
@@ -77,3 +78,13 @@ def test_c_host_matches_python_shim(tmp_path):
     np.testing.assert_array_equal(att, pred["attention_distribution"].cpu().numpy())
     np.testing.assert_array_equal(spa, pred["spatial_distribution"].cpu().numpy())
     np.testing.assert_array_equal(con, pred["contacting_distribution"].cpu().numpy())
+    # ---- the two-clip call by pointer tables == the shim's pack_clips(copy=False) of the same two clips
+    from nl_vsgg_amd.lib.sttran import pack_clips
+    ce = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) and k != "frame_counts" else v) for k, v in e.items()}
+    two = m(pack_clips([ce, dict(ce)], copy=False))
+    torch.cuda.synchronize()
+    got2 = np.fromfile(o2path, dtype=np.float32)
+    assert got2.size == 2 * P * 26
+    np.testing.assert_array_equal(got2[:2 * P * 3].reshape(2 * P, 3), two["attention_distribution"].cpu().numpy())
+    np.testing.assert_array_equal(got2[2 * P * 3:2 * P * 9].reshape(2 * P, 6), two["spatial_distribution"].cpu().numpy())
+    np.testing.assert_array_equal(got2[2 * P * 9:].reshape(2 * P, 17), two["contacting_distribution"].cpu().numpy())
