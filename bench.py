@@ -633,7 +633,8 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
                 traffic, traffic_src, traffic_commit = cls["hbm_bytes_per_launch"], f"profiles/{pmc[-1]}", pj.get("commit")
         by_kernel, by_shape = by_kernel_tables(entries, prof["forwards"])
         res["roofline"] = {
-            "kernel": "gemm_sk_kernel + gemm_fixup_kernel (fp32 MFMA 32x32x2, all nn.Linear / conv3x3 launches)",
+            "kernel": "gemm16_kernel / gemm16c_kernel (v_mfma_f32_16x16x4_f32 tiles 128x176, 128x128, 256x128: nn.Linear launches "
+                      "of >= 1 024 rows, conv3x3) + gemm_sk_kernel (32x32x2 tiles: the rest) + their fix-up launches",
             "bound": "mfma", "achieved": ach,
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_unit": "bytes per launch (L2 fabric reads x2 + writes)",

@@ -317,6 +317,15 @@ __device__ __forceinline__ void tile_origin(int tile, int tiles_m, int tiles_n, 
   tn = g * GN + (local - tm * gn);
 }
 
+// the same with the group width as a run-time value (the 16x16x4 kernels: tuned per launch shape by the launcher)
+__device__ __forceinline__ void tile_origin_rt(int tile, int tiles_m, int tiles_n, int gn_max, int& tm, int& tn) {
+  const int per_group = tiles_m * gn_max;
+  const int g = tile / per_group, local = tile - g * per_group;
+  const int gn = min(gn_max, tiles_n - g * gn_max);
+  tm = local / gn;
+  tn = g * gn_max + (local - tm * gn);
+}
+
 // ---- stream-K schedule ------------------------------------------------------------------------
 // The iteration space (output tile, K-step) is cut into gridDim.x equal contiguous ranges, one per
 // persistent workgroup, so every CU does the same number of MFMA steps whatever the tile count

@@ -82,19 +82,13 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
   const int blk = xcd_remap(blockIdx.x, G);
   const int tiles_dp = dp_per_wg * G;
   const SkRange rg = blk < g_sk ? sk_range(blk, sk_base, sk_rem) : SkRange{0, 0};
-  // PHASE DIVERSITY.  Every workgroup runs the same number of equally long tiles, so left alone all of them reach the end
-  // of a tile at the same moment and 512 workgroups store (and read residuals for) 45 MB of C at once: the burst takes
-  // ~12 us to drain, the operand loads of every next tile queue behind it, and neither resident of a CU has MFMAs to
-  // issue (measured with s_memtime: 13-15 us from the last MFMA of a tile to its last store; 4.4 K-steps of a 61-step
-  // tile).  The stream-K range of a workgroup is therefore cut at the tile border it crosses: the part in front of the
-  // border runs BEFORE the whole tiles, the rest after them (a range that crosses no border goes first or last by
-  // parity).  The lengths of the leading parts are spread evenly over 0 .. range length, so the tile ends of the chip are
-  // spread over time instead of coinciding; which workgroup computes what -- and the parked partials -- are unchanged.
-  int pre_end = rg.begin;
-  if (half < (int)gridDim.x && rg.end > rg.begin) {
-    const int border = (rg.begin / ksteps + 1) * ksteps;            // first tile border behind the start of the range
-    pre_end = border < rg.end ? border : ((blk & 1) ? rg.end : rg.begin);
-  }
+  // Every workgroup runs its whole tiles first and its stream-K range last, in step with its neighbours: the 64
+  // workgroups of an XCD then work on one compact block of tiles at any moment and share its operand panels through that
+  // XCD's L2.  (Round 3 tried to DE-synchronise them -- the stream-K range cut at the tile border it crosses and its
+  // leading part run first, so that tile ends are spread over time instead of 512 workgroups storing 45 MB of C at once:
+  // no faster, 140.3-141.0 vs 141.8-142.1 TFLOP/s, and 2.3 x the fabric reads, 3.3 vs 1.4 GB per [21120,1936,1936]
+  // launch (rocprofv3 FETCH_SIZE), because workgroups that drift apart stop sharing panels.)
+  const int pre_end = rg.begin;
 
   int dp_done = 0;
   for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {
@@ -112,7 +106,7 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
     }
     const int nsteps = ks1 - ks0;
     int tile_m, tile_n;
-    tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
+    tile_origin_rt(tile, tiles_m, tiles / tiles_m, half, tile_m, tile_n);     // `half` = N-tiles per group of the tile order
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef STTRAN_GEMM_EXPERIMENT
     unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
@@ -316,7 +310,7 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
 template <class T, class Epi>
 __global__ void __launch_bounds__(T::NT)
 gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
-                    const float* __restrict__ slab, Epi epi) {
+                    int group_n, const float* __restrict__ slab, Epi epi) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB;
   const int tile = blockIdx.x;
   const int t0 = tile * ksteps, t1 = t0 + ksteps;
@@ -341,7 +335,7 @@ gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk
   }
   const int gt = tiles_dp + tile;
   int tile_m, tile_n;
-  tile_origin<T::GROUP_N>(gt, tiles_m, tiles_n, tile_m, tile_n);
+  tile_origin_rt(gt, tiles_m, tiles_n, group_n, tile_m, tile_n);
   const int row = tile_m * BM + wave * 32 + 16 * i + fr;
   const int col = tile_n * BN + 16 * j + 4 * fg;
   if (row < M) epi.vec(row, col, acc);

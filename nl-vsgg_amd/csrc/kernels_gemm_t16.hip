@@ -54,15 +54,17 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
   bool split = false;
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
-  static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
-  const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
+  // N-tiles per group of the tile order (consecutive tile indices sweep `half` N-tiles of one M-tile, then the next M-tile):
+  // the 64 workgroups of an XCD hold a (64 / half) x half block of tiles whose panels they share through its L2
+  static const int env_gn = getenv("STTRAN_T16_GROUP_N") ? atoi(getenv("STTRAN_T16_GROUP_N")) : 0;
+  const int half = env_gn > 0 ? env_gn : T::GROUP_N;
   const Epi e{epi};
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
                      base, rem, half, slab, e);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess || !split) return err;
   hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps,
-                     sp.g_sk, base, rem, tiles - sp.tiles_sk, slab, e);
+                     sp.g_sk, base, rem, tiles - sp.tiles_sk, half, slab, e);
   return hipGetLastError();
 }
 

@@ -221,9 +221,9 @@ const char* tile_name(int tile) {
     case TILE_128x128: return "128,128,2,2";
     case TILE_128x64: return "128,64,2,2";
     case TILE_64x64: return "64,64,2,2";
-    case TILE_128x176: return "128,176,4,1";
-    case TILE_256x176: return "256,176,8,1";
-    case TILE_T128x128: return "128,128,4,1";
+    case TILE_128x176: return "128,176";
+    case TILE_256x176: return "256,176";
+    case TILE_T128x128: return "128,128";
     default: return "?";
   }
 }
@@ -291,8 +291,10 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     }
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
+  const bool t16 = plan.tile == TILE_128x176 || plan.tile == TILE_256x176 || plan.tile == TILE_T128x128;
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
-               std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
+               t16 ? std::string("gemm16_kernel<Tile16<") + tile_name(plan.tile) + ">,EpiLinear>"
+                   : std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
   HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>(), 1));
   return STTRAN_OK;
 }

@@ -140,6 +140,46 @@ def test_gatherer_rejects_overflow():
         dist.destroy_process_group()
 
 
+def _worker_gathered(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank knows every rank's layout (a deterministic assignment): `gathered` hands out the raw buffers without
+        # reading the clip records back -- what bench.py's strong-scaling loop uses on rank 0
+        rows_of = [3, 5]
+        g = PredictionGatherer(rows_cap=6, clips_cap=1, cols=26, depth=2)
+        ok = True
+        for step in range(3):
+            t = g.submit(_rows(rank, rows_of[rank], step), [rank], [rows_of[rank]])
+            buf, rec = g.gathered(t)
+            ok = ok and tuple(buf.shape) == (world, 6, 26) and tuple(rec.shape) == (world, 1, 2)
+            for r in range(world):
+                ok = ok and torch.equal(buf[r, :rows_of[r]], _rows(r, rows_of[r], step)) and rec[r, 0].tolist() == [r, rows_of[r]]
+        try:
+            g.gathered(0)                                  # two submits ago: its buffer set has been reused
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_gathered_hands_out_raw_buffers_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gathered, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 def _worker_overflow(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -225,3 +225,36 @@ def test_dsg_detr_is_enqueue_only_and_capturable():
     bad = dict(e); bad["labels"] = keep["labels"].clone(); bad["labels"][2] = 99; bad["distribution"] = keep["distribution"].clone()
     with pytest.raises(IndexError):
         m(bad)
+
+
+def test_by_pointer_batch_is_enqueue_only_and_capturable(weights):
+    """a batch handed over as per-clip pointer tables: with the frame counts given and check_indices off the forward only
+    enqueues (the chunk table is re-uploaded only when a call's pointers change), so a step that packs by pointer can be
+    captured into a HIP graph and replayed on new feature VALUES in the same tensors"""
+    from nl_vsgg_amd.lib.sttran import pack_clips
+    m = _model(weights)
+    m.check_indices = False
+    clips = [_cuda_entry(syn.make_entry(700 + i, c)) for i, c in enumerate([[3, 2, 4], [5, 1], [2, 2, 2, 2]])]
+    want = {k: v.clone() for k, v in m(pack_clips(clips, copy=False)).items() if k in OUT_KEYS}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m(pack_clips(clips, copy=False)); m(pack_clips(clips, copy=False))
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m(pack_clips(clips, copy=False))
+    g.replay()
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        assert torch.equal(out[k], want[k]), k
+    # new values in the SAME tensors of one clip: the replay reads them where they are
+    clips[1]["features"].mul_(0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = m(pack_clips(clips, copy=False))
+    torch.cuda.synchronize()
+    for k in OUT_KEYS:
+        assert torch.equal(out[k], fresh[k]), k
+    assert not torch.equal(out["attention_distribution"], want["attention_distribution"])
+    m.sync_check()

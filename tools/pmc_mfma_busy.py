@@ -32,6 +32,16 @@ def main():
             out[c] = float(t["Counter_Value"].mean())
             launches = len(t)
     d = {}
+    # shader clock of the PROFILED launches: GRBM_GUI_ACTIVE per XCD / kernel duration (profiled passes run at a lower
+    # clock than unprofiled ones: MI355X_MICROARCH.md)
+    fs = glob.glob(f"{prefix}GRBM_GUI_ACTIVE/*/*kernel_trace.csv")
+    if fs and "GRBM_GUI_ACTIVE" in out:
+        k = pd.read_csv(fs[0])
+        k = k[k["Kernel_Name"].str.contains(pattern, regex=False) & ~k["Kernel_Name"].str.contains("fixup")]
+        if len(k):
+            dur_ns = float((k["End_Timestamp"] - k["Start_Timestamp"]).mean())
+            d["profiled_kernel_us"] = dur_ns / 1e3
+            d["shader_clock_ghz_profiled"] = (out["GRBM_GUI_ACTIVE"] / 8.0) / dur_ns
     if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
         d["mfma_busy_fraction"] = (out["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (out["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_WAVE_CYCLES" in out:

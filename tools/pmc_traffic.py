@@ -17,7 +17,7 @@ import sys
 
 import pandas as pd
 
-CLASSES = [("gemm", r"gemm(_sk|16)_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)|gemm(16)?_fixup(_vec)?_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn)"),
+CLASSES = [("gemm", r"gemm(_sk|16c?)_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)|gemm(16c?)?_fixup(_vec)?_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)"),
            ("union_conv", r"EpiUnion"), ("attention", r"attention"), ("layernorm", r"layernorm"),
            ("mask_conv", r"mask_conv1_pool"), ("index", r"pair_prep|gather_rows|objcls")]
 

@@ -40,7 +40,7 @@ for c in FETCH_SIZE WRITE_SIZE; do pmc dsg $c --model dsgdetr --steps 3 --warmup
 python3 tools/pmc_traffic.py "$O/${P}_pmc_dsg_FETCH_SIZE" "$O/${P}_pmc_dsg_WRITE_SIZE" "$C" 64 > "$O/${P}_pmc_traffic_dsgdetr_16x12.json"
 # 3. MFMA-pipe occupancy of the dominant kernels (one counter per pass)
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do pmc busy $c --steps 3 --warmup 1; done
-for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "GemmTile<256, 128, 4, 2, 4>" "GemmTile<256, 128, 4, 2, 2>"; do
+for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "EpiUnionT16" "EpiConvT16"; do
   tag=$(echo "$k" | tr -c 'A-Za-z0-9' '_' | cut -c1-40)
   python3 tools/pmc_mfma_busy.py "$O/${P}_pmc_busy_" "$k" "$C" > "$O/${P}_pmc_mfma_busy_$tag.json"
 done
