@@ -257,6 +257,59 @@ __device__ __forceinline__ void epi_linear_strip(const EpiLinear& e, int row, co
   else epi_linear_strip_t<NV, true, true, true>(e, row, cols, acc);
 }
 
+// Both rows of a wave's tile in ONE load -> store phase, for the two epilogue forms of the big launches: bias + residual
+// (out-proj, FFN2) and bias + per-slot position bias (QKV of the middle decoder layers, encoder QKV with neither).  The
+// bias strip is shared by the two rows, so the operands are 3 NV vectors next to the 2 NV accumulators.  Returns false
+// (nothing done) for the forms it does not cover: output scatter (out_rowidx / out_rowidx2), residual AND position bias.
+template <int NV>
+__device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (&rows)[2], const bool (&valid)[2],
+                                                 const int (&cols)[NV], const f32x4 (&acc)[2][NV]) {
+  const bool hrb = e.rowbias != nullptr, hrs = e.res != nullptr;
+  if (e.out_rowidx || e.out_rowidx2 || (hrb && hrs) || e.scale) return false;
+  const bool hb = e.bias != nullptr;
+  f32x4 b[NV], x[2][NV];
+  const float* src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = valid[i] ? rows[i] : rows[0];              // an invalid row re-reads row 0's operands and is not stored
+    src[i] = hrs ? e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[r] : r) * e.ldres
+                 : hrb ? e.rowbias + (int)e.rowslot[r] * e.rb_ld : nullptr;
+  }
+  const int rbmax = e.rb_cols - 4;
+  if (hb) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) b[j] = *reinterpret_cast<const f32x4*>(e.bias + cols[j]);
+  }
+  if (hrs || hrb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) x[i][j] = *reinterpret_cast<const f32x4*>(src[i] + (hrb ? min(cols[j], rbmax) : cols[j]));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!valid[i]) continue;
+    float* dst = e.C + (int64_t)rows[i] * e.ldc;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      f32x4 w = hb ? acc[i][j] + b[j] : acc[i][j];
+      if (hrb) {
+        const f32x4 w2 = w + x[i][j];
+        const bool in = cols[j] < e.rb_cols;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = in ? w2[c] : w[c];
+      }
+      if (e.relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = relu_nan(w[c]);
+      }
+      if (hrs) w += x[i][j];
+      *reinterpret_cast<f32x4*>(dst + cols[j]) = w;
+    }
+  }
+  return true;
+}
+
 // element-wise functors (heads, unaligned outputs) get a vec() that falls back to four scalar calls
 template <class Epi>
 struct EpiScalar4 {

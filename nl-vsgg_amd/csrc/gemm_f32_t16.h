@@ -253,7 +253,14 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
       // 176-column tile has no registers for a whole row's operands next to its 88 accumulator registers (it spills):
       // its rows go in two halves (measured: 140.2 vs 138.2 TFLOP/s on [21120,1936,1936] + residual; the 128-column
       // tile gains 1 % from whole rows)
-      if constexpr (NB <= 8) {
+      int colsall[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) colsall[j] = col0 + 16 * j;
+      const int rows2[2] = {row0, row0 + 16};
+      const bool valid2[2] = {row0 < M, row0 + 16 < M};
+      // the common forms (bias + residual, bias + position bias, bias only): both rows in one load -> store phase
+      if (epi_linear_rows2<NB>(epi.e, rows2, valid2, colsall, acc)) {
+      } else if constexpr (NB <= 8) {
         int cols[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) cols[j] = col0 + 16 * j;
