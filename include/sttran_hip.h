@@ -325,6 +325,8 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
                          int32_t relu, void* stream);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
 int sttran_debug_mfma_peak(int32_t iters, double* tflops);
+/* The tile id (1..8, see csrc/kernels.h) the planner picks for an [M,N,K] nn.Linear GEMM on the current device. */
+int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */
 int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                            int64_t rows, int64_t dim, void* stream);

@@ -1383,6 +1383,11 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return -STTRAN_ERR_INVALID;
+  return plan_gemm(M, N, K, 0, 0).tile;
+}
+
 int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
   if (iters <= 0 || !tflops) return STTRAN_ERR_INVALID;
   float* out = nullptr;

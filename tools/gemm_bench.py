@@ -124,9 +124,9 @@ def main():
             err1 = (Cc.double() - ref).abs().max().item()
             print(f"     bf16x3: {us:9.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF-equivalent   max|err| vs fp64: x3 {err3:.3e}  fp32-MFMA {err1:.3e}")
         auto = rows[0]
-        print(f"{name:10s} M={M:6d} N={N:6d} K={K:5d}  auto {auto[2]:9.1f} us {auto[3]:6.1f} TF | best "
+        print(f"{name:10s} M={M:6d} N={N:6d} K={K:5d}  auto[{TILES.get(lib.sttran_debug_plan_tile(M, N, K), '?')}] {auto[2]:9.1f} us {auto[3]:6.1f} TF | best "
               f"{TILES[best[0]]}/p{best[1]} {best[2]:9.1f} us {best[3]:6.1f} TF")
-        print("     " + "  ".join(f"{TILES[t]}/p{s}:{tf:5.1f}" for t, s, us, tf in rows[1:]))
+        print("     " + "  ".join(f"{TILES[t]}/p{s}:{tf:5.1f} ({us:.1f} us)" for t, s, us, tf in rows[1:]))
 
 
 if __name__ == "__main__":
