@@ -271,7 +271,8 @@ __device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (
   const float* src[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = valid[i] ? rows[i] : rows[0];              // an invalid row re-reads row 0's operands and is not stored
+    // a row past M is not stored; its loads go to a row that exists (the lane's other row, else row 0 of the matrix)
+    const int r = valid[i] ? rows[i] : (valid[0] ? rows[0] : 0);
     src[i] = hrs ? e.res + (int64_t)(e.res_rowidx ? e.res_rowidx[r] : r) * e.ldres
                  : hrb ? e.rowbias + (int)e.rowslot[r] * e.rb_ld : nullptr;
   }

@@ -197,6 +197,21 @@ __device__ __forceinline__ void stage_load(f32x2 (&v)[MAXU], const float* __rest
       v[u] = *reinterpret_cast<const f32x2*>(src + (int64_t)r * ld + col0 + c2);
   }
 }
+// the same without branches: a granule outside the matrix reads the block's first element (always there) and is zeroed
+// by a select -- with every load of a workgroup issued up front (EARLY) the guarded form makes hipcc carry the register
+// arrays through 48 branches as whole tuples and spill them
+template <int NCOLS_PAD, int MAXU>
+__device__ __forceinline__ void stage_load_nb(f32x2 (&v)[MAXU], const float* __restrict__ src, int64_t ld, int nrows_pad,
+                                              int nrows_valid, int col0, int ncols_valid, int tid) {
+  constexpr int HALF = NCOLS_PAD / 2;
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
+    const bool ok = r < nrows_valid && col0 + c2 < ncols_valid;
+    const f32x2 x = *reinterpret_cast<const f32x2*>(ok ? src + (int64_t)r * ld + col0 + c2 : src);
+    v[u] = f32x2{ok ? x[0] : 0.f, ok ? x[1] : 0.f};
+  }
+}
 template <int NCOLS_PAD, int MAXU>
 __device__ __forceinline__ void stage_store(float* dst, int dstride, const f32x2 (&v)[MAXU], int nrows_pad, float scale,
                                             int tid) {
@@ -212,7 +227,7 @@ __device__ __forceinline__ void stage_store(float* dst, int dstride, const f32x2
 // CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2.  <64,128> needs 70 KB at
 // 80 keys (two workgroups per CU: long windows); <128,256> has half the barriers and is used while the
 // sequences are so short (<= 48 keys) that LDS does not limit residency anyway.
-template <int CHUNK, int VW, int MAXROWS, int MINWG>
+template <int CHUNK, int VW, int MAXROWS, int MINWG, bool EARLY = false>
 __global__ void __launch_bounds__(256, MINWG)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
                        const int* __restrict__ seq_len, const int* __restrict__ q_begin, float* __restrict__ out,
@@ -253,22 +268,8 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   f32x4 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2 rq[UQ], rk[UQ], rv[UV];
-  stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
-  stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, 0, hd, tid);
-#pragma unroll
-  for (int ci = 0; ci < NCH; ++ci) {
-    if (ci) __syncthreads();                      // every wave is done reading the previous chunk
-    stage_store<kChunk, UQ>(Qc, kCStride, rq, Lq16, scale, tid);
-    stage_store<kChunk, UQ>(Kc, kCStride, rk, Lk16, 1.f, tid);
-    __syncthreads();
-    if (ci + 1 < NCH) {
-      stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, (ci + 1) * kChunk, hd, tid);
-      stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, (ci + 1) * kChunk, hd, tid);
-    } else {
-      stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
-    }
-    __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of the MFMAs
+  f32x2 rv[UV];
+  auto score_tiles = [&]() {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = wave + 4 * t;
@@ -289,6 +290,46 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
         acc[t] = c0a + c1a;
       }
     }
+  };
+  if constexpr (EARLY) {
+    // sequences of <= 32 keys: every operand of the workgroup is 96 registers per thread, so ALL global loads -- both Q / K
+    // chunks and the V block -- are issued before anything else and the workgroup waits for memory once instead of once
+    // per chunk (with 22 keys the MFMAs of a chunk are far too short to cover the next chunk's round trip)
+    static_assert(NCH == 2, "two head-dim chunks");
+    f32x2 rq0[UQ], rk0[UQ], rq1[UQ], rk1[UQ];
+    stage_load_nb<kChunk, UQ>(rq0, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
+    stage_load_nb<kChunk, UQ>(rk0, qp + dim, ld, Lk16, L, 0, hd, tid);
+    stage_load_nb<kChunk, UQ>(rq1, qp + (int64_t)qb * ld, ld, Lq16, Lq, kChunk, hd, tid);
+    stage_load_nb<kChunk, UQ>(rk1, qp + dim, ld, Lk16, L, kChunk, hd, tid);
+    stage_load_nb<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
+    stage_store<kChunk, UQ>(Qc, kCStride, rq0, Lq16, scale, tid);
+    stage_store<kChunk, UQ>(Kc, kCStride, rk0, Lk16, 1.f, tid);
+    __syncthreads();
+    score_tiles();
+    __syncthreads();                                // every wave is done reading the first chunk
+    stage_store<kChunk, UQ>(Qc, kCStride, rq1, Lq16, scale, tid);
+    stage_store<kChunk, UQ>(Kc, kCStride, rk1, Lk16, 1.f, tid);
+    __syncthreads();
+    score_tiles();
+  } else {
+  f32x2 rq[UQ], rk[UQ];
+  stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
+  stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, 0, hd, tid);
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci) {
+    if (ci) __syncthreads();                      // every wave is done reading the previous chunk
+    stage_store<kChunk, UQ>(Qc, kCStride, rq, Lq16, scale, tid);
+    stage_store<kChunk, UQ>(Kc, kCStride, rk, Lk16, 1.f, tid);
+    __syncthreads();
+    if (ci + 1 < NCH) {
+      stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, (ci + 1) * kChunk, hd, tid);
+      stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, (ci + 1) * kChunk, hd, tid);
+    } else {
+      stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of the MFMAs
+    score_tiles();
+  }
   }
   // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
 #pragma unroll
@@ -373,7 +414,7 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
 }
 
 // dynamic-LDS limits already raised per device, shared by both launchers (a second set of marks could LOWER a limit)
-static DeviceMarks g_attn_marks[2], g_attn_marks_long;
+static DeviceMarks g_attn_marks[3], g_attn_marks_long;
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
@@ -387,8 +428,10 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
     const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
     const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
-    auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    hipError_t e = g_attn_marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    const bool early = l16 <= 32;                      // every operand of a workgroup fits its registers: one memory wait
+    auto kern = early ? attention_short_kernel<128, 256, 32, 4, true>
+                      : small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
+    hipError_t e = g_attn_marks[early ? 2 : small].raise_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, ldo, dim,
                        hd, scale, l16, 0, 1 << 30);
@@ -406,8 +449,8 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
 }
 
 // The same attention when the host does NOT know the sequence lengths (DSG-DETR's class sequences are built on the
-// device): `len_bound` >= every length.  One launch per length class the bound allows -- (0, 48] and (48, 80] on the two
-// short-sequence variants, (80, bound] on the general kernel --, each over all `num_seq` slots; a workgroup whose
+// device): `len_bound` >= every length.  One launch per length class the bound allows -- (0, 32], (32, 48] and (48, 80] on the
+// three short-sequence variants, (80, bound] on the general kernel --, each over all `num_seq` slots; a workgroup whose
 // sequence is empty or belongs to another class returns at once.  No read-back, capturable.
 hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
                                     int len_bound, float* out, int64_t ldo, int dim, int nhead) {
@@ -415,17 +458,18 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
   const int hd = dim / nhead;
   if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)hd);
-  const int edges[3] = {0, 48, kAttnShortMax};
-  for (int v = 0; v < 2; ++v) {
+  const int edges[4] = {0, 32, 48, kAttnShortMax};
+  for (int v = 0; v < 3; ++v) {
     if (len_bound <= edges[v]) break;
-    const bool small = v == 0;
-    const int hi = v == 0 ? 48 : kAttnShortMax;
+    const bool small = v < 2;
+    const int hi = edges[v + 1];
     const int l16 = ((std::min(len_bound, hi) + 15) & ~15);
     const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
     const int region = std::max(2 * l16 * cs, l16 * vs);
     const int lds = (region + l16 * (l16 + 4)) * 4;
-    auto kern = small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    hipError_t e = g_attn_marks[small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    auto kern = v == 0 ? attention_short_kernel<128, 256, 32, 4, true>
+                       : v == 1 ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
+    hipError_t e = g_attn_marks[v == 0 ? 2 : small].raise_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, (const int*)nullptr, out, ldo, dim,
                        hd, scale, l16, edges[v], hi);
