@@ -16,6 +16,7 @@
 #ifndef STTRAN_HIP_H
 #define STTRAN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -325,6 +326,11 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
                          int32_t relu, void* stream);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
 int sttran_debug_mfma_peak(int32_t iters, double* tflops);
+/* Test allocator: `bytes` of device memory (16-byte aligned) that END at the end of a mapping; the address range behind
+ * it is reserved and unmapped, so an access past the buffer is a GPU memory fault, not a silent read of a neighbour.
+ * `cookie` goes to sttran_debug_guarded_free.  STTRAN_ERR_HIP if the driver has no virtual-memory API. */
+int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie);
+int sttran_debug_guarded_free(void* cookie);
 /* The tile id (1..8, see csrc/kernels.h) the planner picks for an [M,N,K] nn.Linear GEMM on the current device. */
 int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */

@@ -26,6 +26,7 @@ inline int64_t pad32(int64_t k) { return (k + 31) / 32 * 32; }
 
 struct Tensor {
   float* d = nullptr;
+  void* d_guard = nullptr;      // STTRAN_GUARD_WORKSPACE: cookie of the guarded allocation behind `d`
   void* planes = nullptr;  // bf16x3 engine: [3][rows][ld] bf16 planes of a GEMM weight (made on demand)
   std::vector<int64_t> shape;
   size_t n = 0;
@@ -33,23 +34,57 @@ struct Tensor {
   bool required = false, loaded = false;
 };
 
+// STTRAN_GUARD_WORKSPACE=1 (tests): every workspace buffer ENDS at the end of its mapping (sttran_debug_guarded_alloc), so
+// a kernel that runs past one faults instead of reading its neighbour
+static bool guard_workspace() {
+  static const bool on = getenv("STTRAN_GUARD_WORKSPACE") && atoi(getenv("STTRAN_GUARD_WORKSPACE")) != 0;
+  return on;
+}
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  void* guard_cookie = nullptr;
   hipError_t ensure(size_t need) {
     if (need <= bytes) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; bytes = 0; }
+    if (p) { hipError_t e = drop(); if (e != hipSuccess) return e; }
     // zero-initialised, 256 bytes of slack: the pad columns of the activation rows (row stride pad32(D)) must be zero
     // and stay zero -- the GEMM A loader reads them for the K tail -- and clamped loads may touch the slack
     need = ((need + 255) & ~size_t(255)) + 256;
-    hipError_t e = hipMalloc(&p, need);
-    if (e != hipSuccess) return e;
+    if (guard_workspace()) {
+      if (sttran_debug_guarded_alloc(need, &p, &guard_cookie) != STTRAN_OK) { p = nullptr; return hipErrorOutOfMemory; }
+    } else {
+      hipError_t e = hipMalloc(&p, need);
+      if (e != hipSuccess) return e;
+    }
     bytes = need;
     return hipMemset(p, 0, need);
   }
-  void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
+  hipError_t drop() {
+    hipError_t e = hipSuccess;
+    if (guard_cookie) sttran_debug_guarded_free(guard_cookie);
+    else if (p) e = hipFree(p);
+    p = nullptr; bytes = 0; guard_cookie = nullptr;
+    return e;
+  }
+  void release() { (void)drop(); }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
+
+// weight tensors: hipMalloc, or a guarded allocation under STTRAN_GUARD_WORKSPACE
+static hipError_t weight_alloc(Tensor& t, size_t bytes) {
+  if (guard_workspace()) {
+    void* p = nullptr;
+    if (sttran_debug_guarded_alloc(bytes, &p, &t.d_guard) != STTRAN_OK) return hipErrorOutOfMemory;
+    t.d = static_cast<float*>(p);
+    return hipSuccess;
+  }
+  return hipMalloc(reinterpret_cast<void**>(&t.d), bytes);
+}
+static void weight_free(Tensor& t) {
+  if (t.d_guard) sttran_debug_guarded_free(t.d_guard);
+  else if (t.d) hipFree(t.d);
+  t.d = nullptr; t.d_guard = nullptr;
+}
 
 struct ProfEvent { hipEvent_t a, b; int cls; int entry; };
 struct ProfKey {
@@ -586,7 +621,7 @@ void sttran_destroy(SttranHandle* h) {
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
   for (auto& kv : h->w) {
-    if (kv.second.d) hipFree(kv.second.d);
+    weight_free(kv.second);
     if (kv.second.planes) hipFree(kv.second.planes);
   }
   if (h->w4_planes) hipFree(h->w4_planes);
@@ -621,14 +656,14 @@ int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const
     // GEMM weight: rows zero-padded to pad32(cols) (B_KMAJOR_PAD contract, csrc/gemm_f32_mfma.h)
     const size_t rows = (size_t)t.shape[0], cols = (size_t)t.shape[1], bytes = rows * (size_t)t.ld * 4 + 256;
     if (!t.d) {
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), bytes));
+      HIPCK(weight_alloc(t, bytes));
       HIPCK(hipMemset(t.d, 0, bytes));
     }
     HIPCK(hipMemcpy2D(t.d, (size_t)t.ld * 4, data, cols * 4, cols * 4, rows, kind));
   } else {
     // 256 zeroed bytes of slack: position_embedding.weight is a GEMM A operand (read up to pad32(K) per row)
     if (!t.d) {
-      HIPCK(hipMalloc(reinterpret_cast<void**>(&t.d), t.n * 4 + 256));
+      HIPCK(weight_alloc(t, t.n * 4 + 256));
       HIPCK(hipMemset(t.d, 0, t.n * 4 + 256));
     }
     HIPCK(hipMemcpy(t.d, data, t.n * 4, kind));
@@ -1381,6 +1416,59 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
   e.res = residual; e.ldres = N;
   hipError_t err = gemm_linear_x3(s, GemmOperand{A, lda, a_rowidx}, planes, ldp, N * ldp, (int)M, (int)N, (int)K, e, slab);
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+// Test allocator: `bytes` of device memory whose end is the end of the mapping -- the page behind it is reserved address
+// space with nothing mapped, so a kernel that reads or writes past a caller's buffer faults instead of silently touching
+// a neighbour (tests/test_guarded_buffers_gpu.py).  HIP virtual-memory API; STTRAN_ERR_HIP where the driver has none.
+namespace {
+struct GuardedAlloc { void* base; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+}
+int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie) {
+  if (!ptr || !cookie || bytes == 0) return STTRAN_ERR_INVALID;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return STTRAN_ERR_HIP;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return STTRAN_ERR_HIP;
+  auto* g = new GuardedAlloc{};
+  g->mapped = (bytes + gran - 1) / gran * gran;
+  g->reserved = g->mapped + gran;                                  // one unmapped granule behind the data
+  bool ok = hipMemAddressReserve(&g->base, g->reserved, gran, nullptr, 0) == hipSuccess;
+  bool created = false, mapped = false;
+  if (ok) ok = created = hipMemCreate(&g->handle, g->mapped, &prop, 0) == hipSuccess;
+  if (ok) ok = mapped = hipMemMap(g->base, g->mapped, 0, g->handle, 0) == hipSuccess;
+  if (ok) {
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = hipMemSetAccess(g->base, g->mapped, &acc, 1) == hipSuccess;
+  }
+  if (!ok) {
+    if (mapped) hipMemUnmap(g->base, g->mapped);
+    if (created) hipMemRelease(g->handle);
+    if (g->base) hipMemAddressFree(g->base, g->reserved);
+    delete g;
+    (void)hipGetLastError();
+    return STTRAN_ERR_HIP;
+  }
+  const size_t span = (bytes + 15) & ~size_t(15);                  // 16-byte aligned start, <= 15 bytes of slack at the end
+  *ptr = static_cast<char*>(g->base) + (g->mapped - span);
+  *cookie = g;
+  return STTRAN_OK;
+}
+int sttran_debug_guarded_free(void* cookie) {
+  if (!cookie) return STTRAN_ERR_INVALID;
+  auto* g = static_cast<GuardedAlloc*>(cookie);
+  hipDeviceSynchronize();
+  hipMemUnmap(g->base, g->mapped);
+  hipMemRelease(g->handle);
+  hipMemAddressFree(g->base, g->reserved);
+  delete g;
+  return STTRAN_OK;
 }
 
 int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K) {
