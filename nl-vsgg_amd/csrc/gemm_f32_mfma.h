@@ -519,7 +519,7 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         // The union conv needs K % 32 == 0 (checked by the launcher): a K-step is never partial.
         kok_a = (k0 + kq4) < k_end;
         kok_b = UFLAT ? k0 < k_end : kok_a;
-        ka = kok_a ? k0 : 0;
+        ka = kok_a ? k0 : -kq4;                    // out of range: the row's first 16 bytes (pa / pb carry + kq4; K may be < 32)
         kb_src = UFLAT ? (kok_b ? k0 * kUHW : 0) : (CONV ? k0 + kq4 : ka);
       }
     };

@@ -47,6 +47,11 @@ def p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def step(*what):
+    """the case about to run, on stderr: after a fault the last line names the culprit"""
+    print("RUN", *what, file=sys.stderr, flush=True)
+
+
 def run_gemm():
     gen = torch.Generator().manual_seed(5)
     cases = [(2240, 1936, 1936), (4410, 2048, 1936), (1100, 1936, 2048), (176, 1936, 1936), (330, 5808, 1936), (129, 352, 100),
@@ -64,6 +69,7 @@ def run_gemm():
                 continue
             if tile == 7 and N % 128:
                 continue
+            step("padded", M, N, K, "tile", tile)
             gC = guarded(torch.full((M, N), float("nan")))
             rc = lib.sttran_debug_gemm_padded(p(gA), Kp, None, p(gW), Kp, p(gb), p(gres), p(gC), M, N, K, 1, tile, None)
             assert rc == 0, (M, N, K, tile, rc)
@@ -71,6 +77,59 @@ def run_gemm():
             err = (gC.cpu().double() - ref).abs().max().item()
             assert err < 2e-3, (M, N, K, tile, err)
             n += 1
+    # gathered A rows (subj / obj FC, last-layer row pruning) and the bias-only / no-epilogue forms
+    M, N, K, R = 700, 1936, 1936, 300
+    Kp = (K + 31) // 32 * 32
+    A = torch.randn(R, Kp, generator=gen)
+    W = torch.zeros(N, Kp); W[:, :K] = torch.randn(N, K, generator=gen) * 0.05
+    b = torch.randn(N, generator=gen)
+    idx = torch.randint(0, R, (M,), generator=gen, dtype=torch.int32)
+    ref = A[idx.long(), :K].double() @ W[:, :K].double().T
+    gA, gW, gb, gidx = guarded(A), guarded(W), guarded(b), guarded(idx)
+    for tile in range(0, 8):
+        if tile == 7:
+            continue
+        for bias in (gb, None):
+            step("gathered", M, N, K, "tile", tile, "bias", bias is not None)
+            gC = guarded(torch.full((M, N), float("nan")))
+            assert lib.sttran_debug_gemm_padded(p(gA), Kp, p(gidx), p(gW), Kp, p(bias), None, p(gC), M, N, K, 0, tile, None) == 0
+            torch.cuda.synchronize()
+            err = (gC.cpu().double() - ref - (b.double() if bias is not None else 0)).abs().max().item()
+            assert err < 2e-3, ("gather", tile, err)
+            n += 1
+    # arbitrary operands (the zero-select loader): K is not a multiple of 32 and nothing is padded
+    for M, N, K in ((33, 70, 100), (257, 129, 36), (300, 26, 1936), (200, 1024, 2376), (1, 3, 4)):
+        A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) * 0.05
+        b, res = torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+        ref = A.double() @ W.double().T + b.double() + res.double()
+        gA, gW, gb, gres = guarded(A), guarded(W), guarded(b), guarded(res)
+        for tile in (0, 1, 2, 3, 4):
+            step("select", M, N, K, "tile", tile)
+            gC = guarded(torch.full((M, N), float("nan")))
+            assert lib.sttran_debug_gemm(p(gA), None, p(gW), p(gb), p(gres), p(gC), M, N, K, 0, tile, 1, None) == 0
+            torch.cuda.synchronize()
+            err = (gC.cpu().double() - ref).abs().max().item()
+            assert err < 2e-3, ("select", M, N, K, tile, err)
+            n += 1
+    # attention and LayerNorm on exactly-sized buffers
+    D, H = 1936, 8
+    for nseq, L in ((15, 22), (16, 11), (3, 35), (3, 70), (2, 81), (1, 500), (5, 32), (5, 33)):
+        tokens = nseq * L
+        step("attention / layernorm", nseq, L)
+        qkv = guarded(torch.randn(tokens, 3 * D, generator=gen))
+        out = guarded(torch.full((tokens, D), float("nan")))
+        off = guarded((torch.arange(nseq, dtype=torch.int32) * L).contiguous())
+        ln = guarded(torch.full((nseq,), L, dtype=torch.int32))
+        assert lib.sttran_debug_attention(p(qkv), p(off), p(ln), nseq, L, p(out), tokens, D, H, None) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        x, g, bt = guarded(torch.randn(tokens, D, generator=gen)), guarded(torch.rand(D, generator=gen)), guarded(torch.randn(D, generator=gen))
+        y = guarded(torch.full((tokens, D), float("nan")))
+        assert lib.sttran_debug_layernorm(p(x), p(g), p(bt), p(y), tokens, D, None) == 0
+        torch.cuda.synchronize()
+        want = torch.nn.functional.layer_norm(x.cpu().double(), (D,), g.cpu().double(), bt.cpu().double(), 1e-5)
+        assert (y.cpu().double() - want).abs().max().item() < 1e-4
+        n += 2
     print("OK gemm %d launches" % n)
 
 
