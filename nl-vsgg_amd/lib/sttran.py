@@ -16,9 +16,12 @@ CPU path: without the HIP library (or without a GPU) construction of the handle 
 """
 from __future__ import annotations
 
+import atexit
 import collections
 import ctypes as C
+import sys
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -34,6 +37,22 @@ def _host_i32(x):
     if isinstance(x, torch.Tensor):
         x = x.detach().cpu().numpy()
     return np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+
+
+# Every model that owns a native handle; destroyed at interpreter exit BEFORE modules (and with them the HIP runtime's
+# Python-side owners) are torn down.  atexit handlers run last-registered first: this module is imported after torch.
+_LIVE = weakref.WeakSet()
+
+
+def _destroy_live_handles():
+    for m in list(_LIVE):
+        try:
+            m._destroy()
+        except Exception:
+            pass
+
+
+atexit.register(_destroy_live_handles)
 
 
 class STTran:
@@ -142,6 +161,7 @@ class STTran:
         if rc != nat.STTRAN_OK:
             raise nat.SttranError(rc, "sttran_create failed")
         self._handle = h
+        _LIVE.add(self)
         if self._sd:
             self._upload()
 
@@ -176,6 +196,11 @@ class STTran:
             self._engine_set = None
 
     def __del__(self):
+        # Never during interpreter shutdown: module teardown order is arbitrary and the HIP runtime underneath
+        # sttran_destroy may already be gone (an intermittent abort AFTER a green test run).  Handles that are still
+        # alive then were destroyed by the atexit hook below, while everything was intact.
+        if sys.is_finalizing():
+            return
         try:
             self._destroy()
         except Exception:
