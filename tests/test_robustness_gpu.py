@@ -1,6 +1,8 @@
 """State that survives between calls on one handle must never change a later call's result:
 stale workspace contents (a NaN clip followed by a smaller clean clip), the cached index maps
 (workspace growth, a failed call in between) and per-device launch state (two handles on two GPUs)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -258,3 +260,29 @@ def test_by_pointer_batch_is_enqueue_only_and_capturable(weights):
         assert torch.equal(out[k], fresh[k]), k
     assert not torch.equal(out["attention_distribution"], want["attention_distribution"])
     m.sync_check()
+
+
+def test_interpreter_exit_with_live_models_is_clean():
+    """models (and a captured graph) still alive at interpreter exit: the atexit hook destroys the native handles while the
+    HIP runtime is intact, __del__ stays out of module teardown -- the process exits 0"""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from nl_vsgg_amd.lib import synthetic as syn\n"
+        "from nl_vsgg_amd.lib.sttran import STTran, _LIVE\n"
+        "C = ['__background__'] + [f'c{i}' for i in range(36)]\n"
+        "sd = {k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()}\n"
+        "keep = []\n"
+        "for mode in ('predcls', 'sgdet'):\n"
+        "    m = STTran(mode=mode, attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=C,\n"
+        "               enc_layer_num=1, dec_layer_num=3, transformer_mode='wk', is_wks=True, feat_dim=2048).to('cuda:0')\n"
+        "    m.load_state_dict(sd, strict=False)\n"
+        "    e = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) and k != 'frame_counts' else v)\n"
+        "         for k, v in syn.make_entry(5, [3, 2, 4], mode=mode).items()}\n"
+        "    keep.append((m, m(e)))\n"
+        "assert len(_LIVE) == 2\n"
+        "print('LIVE', len(_LIVE))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LIVE 2" in r.stdout, f"rc={r.returncode}\n{r.stdout[-1000:]}\n{r.stderr[-3000:]}"
