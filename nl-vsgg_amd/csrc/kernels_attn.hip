@@ -181,49 +181,40 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
 constexpr int kAttnShortMax = 80;
 
 // Staging of a [rows][NCOLS_PAD] block in two halves so that the global loads of the NEXT block can be in flight
-// while the MFMAs of the current one run: stage_load pulls this thread's float2 granules into registers (zero for
-// rows / columns outside the matrix), stage_store scales and writes them to LDS.  Rows are 8-byte aligned
-// (head_dim * 4 = 968 bytes); 256 threads; MAXU = most granules per thread (compile time: the arrays stay in VGPRs).
-template <int NCOLS_PAD, int MAXU>
-__device__ __forceinline__ void stage_load(f32x2 (&v)[MAXU], const float* __restrict__ src, int64_t ld, int nrows_pad,
-                                           int nrows_valid, int col0, int ncols_valid, int tid) {
-  constexpr int HALF = NCOLS_PAD / 2;
-  const int total = nrows_pad * HALF;
-#pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
-    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
-    v[u] = f32x2{0.f, 0.f};
-    if (i < total && r < nrows_valid && col0 + c2 < ncols_valid)
-      v[u] = *reinterpret_cast<const f32x2*>(src + (int64_t)r * ld + col0 + c2);
-  }
-}
-// the same without branches: a granule outside the matrix reads the block's first element (always there) and is zeroed
-// by a select -- with every load of a workgroup issued up front (EARLY) the guarded form makes hipcc carry the register
-// arrays through 48 branches as whole tuples and spill them
-template <int NCOLS_PAD, int MAXU>
-__device__ __forceinline__ void stage_load_nb(f32x2 (&v)[MAXU], const float* __restrict__ src, int64_t ld, int nrows_pad,
-                                              int nrows_valid, int col0, int ncols_valid, int tid) {
-  constexpr int HALF = NCOLS_PAD / 2;
-#pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
-    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
-    const bool ok = r < nrows_valid && col0 + c2 < ncols_valid;
-    const f32x2 x = *reinterpret_cast<const f32x2*>(ok ? src + (int64_t)r * ld + col0 + c2 : src);
-    v[u] = f32x2{ok ? x[0] : 0.f, ok ? x[1] : 0.f};
-  }
-}
-template <int NCOLS_PAD, int MAXU>
-__device__ __forceinline__ void stage_store(float* dst, int dstride, const f32x2 (&v)[MAXU], int nrows_pad, float scale,
-                                            int tid) {
-  constexpr int HALF = NCOLS_PAD / 2;
-  const int total = nrows_pad * HALF;
-#pragma unroll
-  for (int u = 0; u < MAXU; ++u) {
-    const int i = tid + u * 256, r = i / HALF, c2 = (i % HALF) * 2;
-    if (i < total) *reinterpret_cast<f32x2*>(dst + r * dstride + c2) = f32x2{v[u][0] * scale, v[u][1] * scale};
-  }
-}
+// while the MFMAs of the current one run: stage_load4_nb pulls this thread's 16-byte granules into registers (zero for
+// rows / columns outside the matrix), stage_store4 scales and writes them to LDS.  256 threads; MAXU4 = most granules per
+// thread (compile time: the arrays stay in VGPRs).
+// Rows of a head are only 8-byte aligned (head_dim * 4 = 968 bytes): V4a8 = four floats at such an address -- global
+// memory takes a 16-byte access there (unaligned access mode; hipcc emits global_load / store_dwordx4 for it).
+// No branches: a granule outside the matrix reads the block's first element (always there) and is zeroed by selects --
+// with guarded loads hipcc carried the register arrays through the branches as whole tuples and spilled them.
+// A granule is all in, all out, or -- the last one of a head whose dimension is 4 k + 2 -- half in: that one is fetched two
+// floats earlier (inside the head) and shifted, so nothing past the head is ever read.
+struct __attribute__((packed, aligned(8))) V4a8 { f32x4 v; };
 
+template <int NCOLS_PAD, int MAXU4>
+__device__ __forceinline__ void stage_load4_nb(f32x4 (&v)[MAXU4], const float* __restrict__ src, int64_t ld, int nrows_valid,
+                                               int col0, int ncols_valid, int tid) {
+  constexpr int Q = NCOLS_PAD / 4;
+#pragma unroll
+  for (int u = 0; u < MAXU4; ++u) {
+    const int i = tid + u * 256, r = i / Q, c = col0 + (i % Q) * 4;
+    const bool row = r < nrows_valid, full = row && c + 3 < ncols_valid, half = row && !full && c + 1 < ncols_valid;
+    const f32x4 x = reinterpret_cast<const V4a8*>((full || half) ? src + (int64_t)r * ld + (half ? c - 2 : c) : src)->v;
+    v[u] = f32x4{full ? x[0] : (half ? x[2] : 0.f), full ? x[1] : (half ? x[3] : 0.f), full ? x[2] : 0.f, full ? x[3] : 0.f};
+  }
+}
+template <int NCOLS_PAD, int MAXU4>
+__device__ __forceinline__ void stage_store4(float* dst, int dstride, const f32x4 (&v)[MAXU4], int nrows_pad, float scale,
+                                             int tid) {
+  constexpr int Q = NCOLS_PAD / 4;
+  const int total = nrows_pad * Q;
+#pragma unroll
+  for (int u = 0; u < MAXU4; ++u) {
+    const int i = tid + u * 256, r = i / Q, c4 = (i % Q) * 4;
+    if (i < total) *reinterpret_cast<f32x4*>(dst + r * dstride + c4) = v[u] * scale;
+  }
+}
 // CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2.  <64,128> needs 70 KB at
 // 80 keys (two workgroups per CU: long windows); <128,256> has half the barriers and is used while the
 // sequences are so short (<= 48 keys) that LDS does not limit residency anyway.
@@ -262,13 +253,13 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   //      chunk, of the first V block) are issued before the MFMAs of chunk c and written to LDS after them, so
   //      only the very first load latency of a workgroup is exposed.
   constexpr int NCH = kHdPad / kChunk;
-  constexpr int UQ = (MAXROWS * (kChunk / 2) + 255) / 256;      // float2 granules per thread of a Q or K chunk
-  constexpr int UV = (MAXROWS * (kVHalf / 2) + 255) / 256;      // ... of a V block
+  constexpr int UQ4 = (MAXROWS * (kChunk / 4) + 255) / 256;     // 16-byte granules per thread of a Q or K chunk
+  constexpr int UV4 = (MAXROWS * (kVHalf / 4) + 255) / 256;     // ... of a V block
   const float* vp = qp + 2 * dim;
   f32x4 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x2 rv[UV];
+  f32x4 rv[UV4];
   auto score_tiles = [&]() {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -291,61 +282,70 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
       }
     }
   };
+  // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
+  auto write_scores = [&]() {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < ntiles) {
+        const int qi = tile / nk, kj = tile - qi * nk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kj * 16 + l15] = acc[t][e];
+      }
+    }
+  };
   if constexpr (EARLY) {
     // sequences of <= 32 keys: every operand of the workgroup is 96 registers per thread, so ALL global loads -- both Q / K
     // chunks and the V block -- are issued before anything else and the workgroup waits for memory once instead of once
     // per chunk (with 22 keys the MFMAs of a chunk are far too short to cover the next chunk's round trip)
     static_assert(NCH == 2, "two head-dim chunks");
-    f32x2 rq0[UQ], rk0[UQ], rq1[UQ], rk1[UQ];
-    stage_load_nb<kChunk, UQ>(rq0, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
-    stage_load_nb<kChunk, UQ>(rk0, qp + dim, ld, Lk16, L, 0, hd, tid);
-    stage_load_nb<kChunk, UQ>(rq1, qp + (int64_t)qb * ld, ld, Lq16, Lq, kChunk, hd, tid);
-    stage_load_nb<kChunk, UQ>(rk1, qp + dim, ld, Lk16, L, kChunk, hd, tid);
-    stage_load_nb<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
-    stage_store<kChunk, UQ>(Qc, kCStride, rq0, Lq16, scale, tid);
-    stage_store<kChunk, UQ>(Kc, kCStride, rk0, Lk16, 1.f, tid);
+    static_assert(NVH == 1, "one V block");
+    f32x4 rq0[UQ4], rk0[UQ4], rq1[UQ4], rk1[UQ4];
+    stage_load4_nb<kChunk, UQ4>(rq0, qp + (int64_t)qb * ld, ld, Lq, 0, hd, tid);
+    stage_load4_nb<kChunk, UQ4>(rk0, qp + dim, ld, L, 0, hd, tid);
+    stage_load4_nb<kChunk, UQ4>(rq1, qp + (int64_t)qb * ld, ld, Lq, kChunk, hd, tid);
+    stage_load4_nb<kChunk, UQ4>(rk1, qp + dim, ld, L, kChunk, hd, tid);
+    stage_load4_nb<kVHalf, UV4>(rv, vp, ld, L, 0, hd, tid);
+    stage_store4<kChunk, UQ4>(Qc, kCStride, rq0, Lq16, scale, tid);
+    stage_store4<kChunk, UQ4>(Kc, kCStride, rk0, Lk16, 1.f, tid);
     __syncthreads();
     score_tiles();
     __syncthreads();                                // every wave is done reading the first chunk
-    stage_store<kChunk, UQ>(Qc, kCStride, rq1, Lq16, scale, tid);
-    stage_store<kChunk, UQ>(Kc, kCStride, rk1, Lk16, 1.f, tid);
+    stage_store4<kChunk, UQ4>(Qc, kCStride, rq1, Lq16, scale, tid);
+    stage_store4<kChunk, UQ4>(Kc, kCStride, rk1, Lk16, 1.f, tid);
     __syncthreads();
     score_tiles();
+    // scores -> LDS, then V over the Q / K region (every wave has read its last fragments: barrier)
+    write_scores();
+    __syncthreads();
+    stage_store4<kVHalf, UV4>(Vs, kVStride, rv, Lk16, 1.f, tid);
   } else {
-  f32x2 rq[UQ], rk[UQ];
-  stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, 0, hd, tid);
-  stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, 0, hd, tid);
+  f32x4 rq[UQ4], rk[UQ4];
+  stage_load4_nb<kChunk, UQ4>(rq, qp + (int64_t)qb * ld, ld, Lq, 0, hd, tid);
+  stage_load4_nb<kChunk, UQ4>(rk, qp + dim, ld, L, 0, hd, tid);
 #pragma unroll
   for (int ci = 0; ci < NCH; ++ci) {
     if (ci) __syncthreads();                      // every wave is done reading the previous chunk
-    stage_store<kChunk, UQ>(Qc, kCStride, rq, Lq16, scale, tid);
-    stage_store<kChunk, UQ>(Kc, kCStride, rk, Lk16, 1.f, tid);
+    stage_store4<kChunk, UQ4>(Qc, kCStride, rq, Lq16, scale, tid);
+    stage_store4<kChunk, UQ4>(Kc, kCStride, rk, Lk16, 1.f, tid);
     __syncthreads();
     if (ci + 1 < NCH) {
-      stage_load<kChunk, UQ>(rq, qp + (int64_t)qb * ld, ld, Lq16, Lq, (ci + 1) * kChunk, hd, tid);
-      stage_load<kChunk, UQ>(rk, qp + dim, ld, Lk16, L, (ci + 1) * kChunk, hd, tid);
+      stage_load4_nb<kChunk, UQ4>(rq, qp + (int64_t)qb * ld, ld, Lq, (ci + 1) * kChunk, hd, tid);
+      stage_load4_nb<kChunk, UQ4>(rk, qp + dim, ld, L, (ci + 1) * kChunk, hd, tid);
     } else {
-      stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, 0, hd, tid);
+      stage_load4_nb<kVHalf, UV4>(rv, vp, ld, L, 0, hd, tid);
     }
     __builtin_amdgcn_sched_barrier(0);            // keep the loads ahead of the MFMAs
     score_tiles();
   }
-  }
-  // C/D of 16x16: col = lane&15 (key), row = 4*(lane>>4) + e (query)
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int tile = wave + 4 * t;
-    if (tile < ntiles) {
-      const int qi = tile / nk, kj = tile - qi * nk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Ps[(qi * 16 + 4 * g + e) * ps + kj * 16 + l15] = acc[t][e];
-    }
-  }
+  write_scores();
   __syncthreads();
+  // the first V block (already in registers) goes to LDS first; the second lands during softmax + PV
+  stage_store4<kVHalf, UV4>(Vs, kVStride, rv, Lk16, 1.f, tid);
+  if (NVH > 1) stage_load4_nb<kVHalf, UV4>(rv, vp, ld, L, kVHalf, hd, tid);
+  }
 
-  // ---- softmax rows (wavefront shuffles); the first V block (already in registers) goes to LDS first ------
-  stage_store<kVHalf, UV>(Vs, kVStride, rv, Lk16, 1.f, tid);
-  if (NVH > 1) stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, kVHalf, hd, tid);     // second block: lands during softmax + PV
+  // ---- softmax rows (wavefront shuffles) ------------------------------------------------------------------------------
   for (int r = wave; r < Lq16; r += 4) {
     float* pr = Ps + r * ps;
     float m = -INFINITY;
@@ -373,8 +373,8 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
   for (int vh = 0; vh < NVH; ++vh) {
     if (vh) {
       __syncthreads();                           // every wave is done with the previous block
-      stage_store<kVHalf, UV>(Vs, kVStride, rv, Lk16, 1.f, tid);
-      if (vh + 1 < NVH) stage_load<kVHalf, UV>(rv, vp, ld, Lk16, L, (vh + 1) * kVHalf, hd, tid);
+      stage_store4<kVHalf, UV4>(Vs, kVStride, rv, Lk16, 1.f, tid);
+      if (vh + 1 < NVH) stage_load4_nb<kVHalf, UV4>(rv, vp, ld, L, (vh + 1) * kVHalf, hd, tid);
       __syncthreads();
     }
     for (int kb = 0; kb < nk; ++kb) {
@@ -391,23 +391,28 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int dt = 0; dt < DTW; ++dt)
-              o[qi][vh * DTW + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bv[dt][e], o[qi][vh * DTW + dt], 0, 0, 0);
+              // V on the "A" port, P on the "B" port: the block comes out transposed, O^T[d][q] -- a lane then holds FOUR
+              // CONSECUTIVE d of one query row (two 8-byte stores) instead of one d of four query rows (four dword stores)
+              o[qi][vh * DTW + dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[dt][e], a[e], o[qi][vh * DTW + dt], 0, 0, 0);
         }
       }
     }
   }
+  // C/D of the transposed block: col = lane & 15 = query row, row = 4 (lane >> 4) + e = d.  Rows of `out` are 16-byte
+  // aligned, a head starts at a multiple of 8 bytes (head_dim is even)
   float* op = out + (int64_t)(base + qb) * ldo + h * hd;
 #pragma unroll
   for (int qi = 0; qi < kMaxQ; ++qi) {
-    if (qi < nq) {
+    const int q = qi * 16 + l15;
+    if (qi < nq && q < Lq) {
+      float* orow = op + (int64_t)q * ldo;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int d = (dt / DTW) * kVHalf + wave * (16 * DTW) + (dt % DTW) * 16 + l15;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int q = qi * 16 + 4 * g + e;
-          if (q < Lq && d < hd) op[(int64_t)q * ldo + d] = o[qi][dt][e];
-        }
+        const int d = (dt / DTW) * kVHalf + wave * (16 * DTW) + (dt % DTW) * 16 + 4 * g;
+        // one 16-byte store at an 8-byte aligned address (global memory takes it: unaligned access mode); the last
+        // group of a head (head_dim 242 = 60 x 4 + 2) is half in
+        if (d + 3 < hd) reinterpret_cast<V4a8*>(orow + d)->v = o[qi][dt];
+        else if (d < hd) *reinterpret_cast<f32x2*>(orow + d) = f32x2{o[qi][dt][0], o[qi][dt][1]};
       }
     }
   }
@@ -420,7 +425,7 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || max_len <= 0) return hipSuccess;
   const int hd = dim / nhead;
-  if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
+  if (hd > kHdPad - 2 || (hd & 1) || hd < 4 || (ldo & 1)) return hipErrorInvalidValue;      // 8-byte accesses of rows and heads
   const float scale = 1.0f / sqrtf((float)hd);
   if (max_len <= kAttnShortMax) {
     const int l16 = (max_len + 15) & ~15;
@@ -456,7 +461,7 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
                                     int len_bound, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || len_bound <= 0) return hipSuccess;
   const int hd = dim / nhead;
-  if (hd > kHdPad - 2 || (hd & 1)) return hipErrorInvalidValue;
+  if (hd > kHdPad - 2 || (hd & 1) || hd < 4 || (ldo & 1)) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)hd);
   const int edges[4] = {0, 32, 48, kAttnShortMax};
   for (int v = 0; v < 3; ++v) {
