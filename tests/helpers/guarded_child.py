@@ -113,7 +113,7 @@ def run_gemm():
             n += 1
     # attention and LayerNorm on exactly-sized buffers
     D, H = 1936, 8
-    for nseq, L in ((15, 22), (16, 11), (3, 35), (3, 70), (2, 81), (1, 500), (5, 32), (5, 33)):
+    for nseq, L in ((15, 22), (16, 11), (3, 35), (3, 70), (2, 81), (1, 500), (5, 32), (5, 33), (1, 1537), (2, 481)):
         tokens = nseq * L
         step("attention / layernorm", nseq, L)
         qkv = guarded(torch.randn(tokens, 3 * D, generator=gen))
@@ -216,8 +216,10 @@ def run_aux():
         for k in keys:
             assert torch.equal(got[k], want[k]), ("dsg", counts, k)
         n += 1
-    for seed, counts in ((301, [25, 0, 31, 18, 22]), (304, [90, 80, 100]), (303, [3])):
-        plain, guard = _entries(syn.make_detector_entry(seed, counts, feat_dim=2048, fmap_channels=5))
+    for seed, counts, fd in ((301, [25, 0, 31, 18, 22], 2048), (304, [90, 80, 100], 2048), (303, [3], 2048),
+                             (811, [1300, 40, 1100], 8)):              # the last: NMS tables in scratch, not in LDS
+        step("select", counts)
+        plain, guard = _entries(syn.make_detector_entry(seed, counts, feat_dim=fd, fmap_channels=5 if fd == 2048 else 2))
         want, got = sgdet_select(plain), sgdet_select(guard)
         torch.cuda.synchronize()
         for k, v in want.items():
@@ -232,7 +234,8 @@ def run_aux():
                                           AG_contacting_predicates=[f"p{i}" for i in range(9, 26)], iou_threshold=0.5)
         ev[tag].register_container()
     rng = np.random.default_rng(9)
-    for seed, counts in ((500, [4, 2, 5, 3]), (501, [120, 100]), (502, [11] * 16)):
+    for seed, counts in ((500, [4, 2, 5, 3]), (501, [120, 100]), (502, [11] * 16), (503, [300, 2])):
+        step("evaluator / union boxes", counts)
         e = syn.make_entry(seed, counts, geometry_only=True)
         gt = syn.make_gt_annotation(seed + 1, e)
         P = e["pair_idx"].shape[0]
