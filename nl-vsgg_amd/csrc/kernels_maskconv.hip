@@ -134,7 +134,12 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
             pool[(r + 4 * fh) * 196 + n] = relu_nan(acc[j][4 * q + r] + cb[r]) * cs[r] + ct[r];
         }
       }
-      __syncthreads();
+      // `pool` is private to this wave and a wave's LDS operations execute in program order: the lanes' writes above are
+      // visible to the reads below without a workgroup barrier (rounds 1-2 had __syncthreads() here and behind the reads:
+      // eight barriers per pair that only made the four waves wait for each other); the compiler must keep the order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int o = lane + 64 * i;
@@ -148,7 +153,9 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
           dst[q * kMcPoolCh + pdst[i]] = m;
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next round's writes stay behind these reads
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
     if (pn < P) {
