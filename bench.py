@@ -870,7 +870,16 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         env.barrier()
-        env.dist.destroy_process_group()
+        # the line is out; a communicator teardown that does not come back must not keep the launcher (and the driver's
+        # clock) waiting: give it 30 s, then leave without it
+        import threading
+        t = threading.Thread(target=env.dist.destroy_process_group, daemon=True)
+        t.start()
+        t.join(30.0)
+        if t.is_alive():
+            print(f"bench.py: rank {rank}: destroy_process_group still running after 30 s, exiting", file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
