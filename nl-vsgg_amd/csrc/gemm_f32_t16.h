@@ -225,13 +225,38 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
       mma_block(NBLK - 1);
       __builtin_amdgcn_sched_barrier(0);
     };
+    // K = 32 k + 16 (1936 = 60.5 K-steps): the second half of the tile's last K-step multiplies by W's zero padding --
+    // that step runs its kb = 0 blocks only (half a step of 61: 0.8 % of the MFMAs of every K = 1936 launch)
+    auto k_half = [&](auto set_c) {
+      constexpr int set = decltype(set_c)::value;
+      const float* cur = smem + set * T::STAGE;
+#pragma unroll
+      for (int sb = 0; sb < NB; ++sb) {
+        if (sb + 1 < NB) {
+          read_b(cur, sb + 1);
+          mma_block(sb);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                                      // every wave has read this stage: the next item may overwrite it
+      mma_block(NB - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
     {
+      const bool half_tail = ABL == 0 && (K & 31) == 16 && ks1 == ksteps;
+      const int nfull = half_tail ? nsteps - 1 : nsteps;
       int t = 0;
-      for (; t + 1 < nsteps; t += 2) {
+      for (; t + 1 < nfull; t += 2) {
         k_step(t, std::integral_constant<int, 0>{});
         k_step(t + 1, std::integral_constant<int, 1>{});
       }
-      if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
+      if (t < nfull) { k_step(t, std::integral_constant<int, 0>{}); ++t; }
+      if (half_tail) {
+        if (t & 1) k_half(std::integral_constant<int, 1>{}); else k_half(std::integral_constant<int, 0>{});
+      }
     }
     if constexpr (ABL == 5) {          // loads issued but never written to LDS: keep them alive, wait for them only here
 #pragma unroll
