@@ -68,6 +68,7 @@ class PredictionGatherer:
         self._works = [None] * depth
         self._meta_cache = {}
         self._n = 0
+        self._overflow_seen = torch.zeros((), device=dev, dtype=torch.int64)   # OVERFLOW records met by `gathered()`
 
     OVERFLOW = -2          # clip id of a record that says "this rank's submit did not fit its capacities"
 
@@ -137,8 +138,20 @@ class PredictionGatherer:
             raise ValueError("that gather's buffers have been reused")
         k = ticket % self.depth
         self._wait(k)
-        return (self._gathered[k].view(self.world, self.rows_cap, self.cols),
-                self._meta_all[k].view(self.world, self.clips_cap, 2))
+        meta = self._meta_all[k].view(self.world, self.clips_cap, 2)
+        # a rank whose submit did not fit sends an OVERFLOW record and no rows: count it where it lives (no read-back
+        # here); `raise_if_overflowed()` -- one synchronisation, whenever the consumer likes -- turns it into the error
+        # `result()` raises, so a consumer of the raw buffers cannot score stale rows without ever hearing of it
+        self._overflow_seen += (meta[:, 0, 0] == self.OVERFLOW).sum()
+        return self._gathered[k].view(self.world, self.rows_cap, self.cols), meta
+
+    def raise_if_overflowed(self):
+        """Synchronises: raises if any gather handed out by `gathered()` carried an OVERFLOW record."""
+        n = int(self._overflow_seen.item())
+        if n:
+            self._overflow_seen.zero_()
+            raise ValueError(f"{n} rank submit(s) exceeded the gatherer's capacities (rows_cap={self.rows_cap}, "
+                             f"clips_cap={self.clips_cap}): the rows handed out by gathered() for them are not predictions")
 
     def result(self, ticket):
         """{clip_id: [pairs, cols] tensor} of the gather `ticket` (views into its buffer set: valid until that set
@@ -183,3 +196,17 @@ def all_gather_predictions(local_rows, local_clip_ids, local_clip_pairs, group=N
     g = PredictionGatherer(rows_cap, clips_cap, cols=local_rows.shape[1], device=dev, group=group, depth=1,
                            dtype=local_rows.dtype)
     return g.result(g.submit(local_rows, local_clip_ids, local_clip_pairs))
+
+
+def all_reduce_recall(evaluator, group=None, device=None):
+    """Recall table of a split whose clips were scored by SEVERAL ranks, each with its own evaluator on its own clips:
+    one all-reduce (SUM) of `evaluator.partial_sums()` -- 2 * (9 + 6 * num_rel) float64 -- and every rank holds the
+    `summary()` of the union.  Replaces "gather every prediction row to rank 0 and score there", which serialises a
+    strong-scaling run on rank 0's evaluator; the all-gather of the rows (`PredictionGatherer`) remains the way to bring
+    the predictions themselves to every rank.  No reference counterpart (single process, `tools/test_STTran.py:62-92`)."""
+    vec = torch.from_numpy(evaluator.partial_sums())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if device is not None:
+            vec = vec.to(device)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    return evaluator.summary_from_partial_sums(vec.cpu().numpy())

@@ -263,6 +263,44 @@ class SceneGraphEvaluator:
             out[t] = {k: float(v) for k, v in self.result_dict[f"{m}_{t}"].items()}
         return out
 
+    # ---- merging evaluators that scored disjoint sets of clips (one per rank) ----------------------------------
+    # Every reported number is a mean of a per-frame list (Recall@K: over all frames; mean Recall@K: per predicate over
+    # the frames that contain it, then over predicates -- `calculate_mean_recall`), so (sum, count) pairs are a sufficient
+    # statistic: ranks score their own clips, add the vectors (`lib/distributed.py::all_reduce_recall`: one all-reduce of
+    # 2 * (9 + 6 * num_rel) float64) and any rank can print the table of the whole split.  The reference has one process
+    # and one evaluator (`tools/test_STTran.py:62-71`); summation order is the only difference (float64, <= 1e-12).
+    def partial_sums(self):
+        m, rd = self.mode, self.result_dict
+        out = []
+        for t in ("recall", "recall_nogc", "semi_recall"):
+            for k in KS:
+                v = rd[f"{m}_{t}"][k]
+                out += [float(np.sum(v, dtype=np.float64)) if len(v) else 0.0, float(len(v))]
+        for t in ("mean_recall", "ng_mean_recall"):
+            for k in KS:
+                for v in rd[f"{m}_{t}_collect"][k]:
+                    out += [float(np.sum(v, dtype=np.float64)) if len(v) else 0.0, float(len(v))]
+        return np.asarray(out, dtype=np.float64)
+
+    def summary_from_partial_sums(self, vec):
+        """`summary()` of the union of the evaluators whose `partial_sums()` were added up into `vec`."""
+        vec = np.asarray(vec, dtype=np.float64).reshape(-1, 2)
+        if vec.shape[0] != 9 + 6 * self.num_rel:
+            raise ValueError("partial-sum vector of another evaluator configuration")
+        out, i = {}, 0
+        for t in ("recall", "recall_nogc", "semi_recall"):
+            out[t] = {}
+            for k in KS:
+                s, n = vec[i]; i += 1
+                out[t][k] = float(s / n) if n > 0 else float("nan")
+        for t in ("mean_recall", "ng_mean_recall"):
+            out[t] = {}
+            for k in KS:
+                per = [float(s / n) if n > 0 else 0.0 for s, n in vec[i:i + self.num_rel]]
+                i += self.num_rel
+                out[t][k] = sum(per) / float(self.num_rel)
+        return out
+
     def print_stats(self, logger=None):
         s = self.summary()
         lines = ["======================" + self.mode + "============================"]

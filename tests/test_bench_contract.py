@@ -7,30 +7,101 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("bench_default_with_cpu.json"))
-    d = json.load(open(os.path.join(ROOT, "profiles", lines[-1])))          # the newest round's default line
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+COMPACT_LIMIT = 4096          # the driver keeps the last 8 KB of stdout: the whole line must be in it
+
+
+def _check_compact(d):
+    for k in CONTRACT:
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
-    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "dominant"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.0 < r["frac"] < 1.0 and r["peak"] == 157.3
+    dom = r["dominant"]
+    assert dom["tflops"] > 0 and 0.0 < dom["frac"] < 1.0 and dom["launches_per_step"] >= 1 and dom["mean_us"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["host_cores"] >= c["cores"]
-    # round 2: per-kernel roofline rows and the second BASELINE workload ride in the same line
-    assert r["by_kernel"] and all(k in r["by_kernel"][0] for k in ("kernel", "launches_per_step", "gflop_per_step", "mean_us"))
-    w = d["workloads"]["64x36"]
-    assert w["value"] > 0 and 0.0 < w["roofline"]["frac"] < 1.0 and w["config"]["frames_per_clip"] == 64
-    assert d["one_clip_per_pass"]["value"] > 0
-    assert abs(d["value"] - d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # value = whole-job frames / time of the timed steps
+    per_step = d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] * d["n_gpus"]
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # scalars only: no table (list of dicts) anywhere in the line
+    def no_tables(x):
+        if isinstance(x, dict):
+            return all(no_tables(v) for v in x.values())
+        if isinstance(x, list):
+            return all(not isinstance(v, (dict, list)) for v in x)
+        return True
+    assert no_tables(d)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """the newest committed default line (profiles/*bench_default_with_cpu.json = stdout of `python bench.py` on the GPU box)
+    is ONE compact line under the driver's capture size, and its detail file carries the tables"""
+    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("bench_default_with_cpu.json")
+                   and not f.startswith(("r1_", "r2_", "r3_")))
+    if not lines:
+        import pytest
+        pytest.skip("no round-4 default line committed yet")
+    raw = open(os.path.join(ROOT, "profiles", lines[-1])).read()
+    assert len(raw.strip().splitlines()) == 1 and len(raw.strip()) < COMPACT_LIMIT
+    d = json.loads(raw)
+    _check_compact(d)
+    assert d["n_gpus"] == 1 and d["one_clip_per_pass"]["value"] > 0 and d["workloads"]["64x36"]["value"] > 0
+    assert d["config"]["layout_cache"].startswith("miss") and d["pcie_inclusive_overlapped"]["value"] > 0
+    det = json.load(open(os.path.join(ROOT, "profiles", lines[-1].replace("bench_default_with_cpu", "bench_default_detail"))))
+    r = det["roofline"]
+    assert r["by_kernel"] and r["by_shape"] and all(k in r["by_kernel"][0] for k in ("kernel", "launches_per_step", "gflop_per_step", "mean_us"))
+    assert det["value"] == d["value"] and det["workloads"]["64x36"]["config"]["frames_per_clip"] == 64
+
+
+def test_compact_line_stays_under_the_driver_capture():
+    """bench.compact_line on a synthetic worst case (8 ranks, every optional block present, long error strings): one JSON
+    line, scalars only, < 4 KB -- round 3's 26 KB line was cut by the driver's 8 KB capture and could not be parsed"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    blk = {"value": 123456.789012, "ms_per_step": 29.123456789, "roofline": {"frac": 0.123456789}, "cpu_baseline": {"value": 81.123456},
+           "one_clip_per_pass": {"value": 15000.123456}, "allgather_ms": 0.123456789, "max_abs_diff_vs_fp32_engine": 1.6093254089355469e-06}
+    ss = {"value": 90413.123456, "seconds": 0.60123456, "clips": 1737, "frames": 54371, "ranks": 8, "busy_max_s": 0.123456789,
+          "eval_max_s": 0.0123456789, "eval_s_rank0": 0.0123456789, "lpt_imbalance": 1.0123456789, "busy_imbalance": 1.0123456789,
+          "gather_verified": True, "recall_with_constraint": {"10": 0.1, "20": 0.1689, "50": 0.2}, "per_rank": [{"rank": i} for i in range(8)]}
+    d = {"metric": "frames/sec (PredCls inference)", "value": 2048 / (25.6123456789 * 1e-3), "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+         "ms_per_step": 25.6123456789, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+         "config": {"workload": "x" * 300, "clips_per_step": 4, "frames_per_clip": 64, "boxes_per_frame": 36, "pairs_per_step": 8960,
+                    "hip_graph": False, "layout_cache": "miss every step: " + "y" * 200, "batch": "z" * 200, "sharding": "w" * 200},
+         "repeats": [80000.123456, 80001.123456, 79999.123456], "ranks_seen": 8, "distinct_devices": 8,
+         "devices": [{"rank": i, "pci_bus_id": "0000:c5:00.0", "uuid": "GPU-" + "a" * 32} for i in range(8)],
+         "roofline": {"bound": "mfma", "achieved": 141.04287222812908, "peak": 157.3, "unit": "TFLOP/s", "frac": 141.04287222812908 / 157.3,
+                      "traffic": 1698316052.7472527, "traffic_source": "profiles/r4_z_pmc_traffic_64x36.json", "traffic_measured_in_run": False,
+                      "algorithmic_bytes_per_launch": 431937565.09090906, "launches_per_step": 22.0, "avg_launch_us": 1100.2403279834173,
+                      "share_of_device_time": 0.8087984440710084, "kernel": "k" * 400,
+                      "dominant": {"name": "gemm16_kernel<Tile16<128,176>,EpiLinear>", "launches_per_step": 13.0, "mean_us": 1290.123456,
+                                   "gflop_per_step": 2381.8123456, "tflops": 142.0123456, "frac": 0.90123456, "share_of_device_time": 0.55123456},
+                      "per_class_ms_per_step": {"gemm": 24.205123, "union_conv": 4.264123, "mask_conv": 0.667123, "attention": 0.541123,
+                                                "layernorm": 0.233123, "index": 0.018123},
+                      "by_kernel": [{"kernel": "k" * 80}] * 12, "by_shape": [{"kernel": "k" * 80}] * 21},
+         "cpu_baseline": {"value": 81.32498323163517, "unit": "frames/s", "cores": 8, "host_cores": 256, "kind": "port", "sample": "s" * 400},
+         "one_clip_per_pass": {"value": 15808.9123, "ms_per_step": 1.0121123}, "same_batch": {"value": 34000.0123, "ms_per_step": 29.9123},
+         "pcie_inclusive_overlapped": {"value": 12000.123, "ms_per_step": 80.0123, "h2d_gb_per_s": 55.0123},
+         "one_rank_alone": {"value": 10345.123, "ms_per_step": 24.7123}, "allgather_ms": 0.0823456, "allgather_bytes_per_rank": 931840,
+         "batch_sweep": [{"clips_per_step": 1, "value": 15808.9}, {"clips_per_step": 16, "value": 31803.8}, {"clips_per_step": 64, "value": 34269.6}],
+         "reference_arithmetic": {"frac_of_fp32_mfma_peak": 0.9756123},
+         "workloads": {"64x36": blk, "16x12": blk, "ag_split_shaped": ss, "16x12_bf16x3": blk, "dsgdetr_16x12": {"error": "e" * 500}},
+         "strong_scaling": {"64x36_x64": ss, "ag_split_shaped": ss}}
+    line = bench.compact_line(d)
+    assert "\n" not in line and len(line) < COMPACT_LIMIT, len(line)
+    c = json.loads(line)
+    _check_compact(c)
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+    assert c["strong_scaling"]["ag_split_shaped"]["eval_s_rank0"] > 0 and c["workloads"]["64x36"]["value"] > 0
 
 
 def test_bench_accepts_the_driver_flags():
@@ -45,23 +116,17 @@ def test_bench_accepts_the_driver_flags():
 
 def test_newest_driver_bench_line_has_the_contract_fields():
     """the DRIVER's own record of the last round (BENCH_rNN.json at the repo root: `parsed` = the line it read from
-    bench.py on a fresh MI355X): the same contract checks as for the committed profile line"""
+    bench.py on a fresh MI355X): the same contract checks as for the committed line.  Round 3's record is the known bad
+    one (a 26 KB line, cut by the driver's 8 KB capture: `parsed` is null) -- the reason bench.py prints a compact line
+    since round 4; it is reported as an expected failure, any later record must parse."""
     import glob
+    import pytest
     files = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")))
     if not files:
-        import pytest
         pytest.skip("no driver bench record in this checkout")
     rec = json.load(open(files[-1]))
     d = rec.get("parsed") or {}
+    if os.path.basename(files[-1]) == "BENCH_r03.json" and not d:
+        pytest.xfail("BENCH_r03.json: the round-3 line (26 KB) exceeded the driver's capture; fixed by compact_line (round 4)")
     assert rec.get("rc", 0) == 0 and d, files[-1]
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, (files[-1], k)
-    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
-    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
-    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0
-    # value = whole-job frames / time of the timed steps
-    per_step = d["config"]["clips_per_step"] * d["config"]["frames_per_clip"] * d["n_gpus"]
-    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    _check_compact(d)

@@ -8,6 +8,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -21,42 +22,61 @@ def _free_port():
         return s.getsockname()[1]
 
 
+COMPACT_LIMIT = 4096
+
+
 def _run(cmd, extra_env=None, timeout=900):
-    env = dict(os.environ)
+    """run bench.py; returns (the ONE compact stdout line, the detail object rank 0 wrote to $BENCH_DETAIL)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        env["BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0
+        assert r.stdout.strip().splitlines()[-1] == lines[0]         # ... and it is the LAST line of stdout
+        assert len(lines[0]) < COMPACT_LIMIT, len(lines[0])          # the driver keeps 8 KB of stdout: the line must fit
+        with open(env["BENCH_DETAIL"]) as f:
+            detail = json.load(f)
+        assert [l for l in r.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
+    return json.loads(lines[0]), detail
 
 
 GLOO_ON_GPU0 = {"BENCH_DIST_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
 
 
-def _check_two_rank_line(d, cps):
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["value"] == d["value"] and d["value"] != float("inf")
-    # N > 1: the headline is the 64x36 clip (BASELINE configs[3]); whole-job frames / max-rank time
-    assert d["config"]["frames_per_clip"] == 64 and d["config"]["boxes_per_frame"] == 36
-    assert abs(d["value"] - 2 * cps * 64 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+def _check_two_rank_line(c, d, cps):
+    """c = the compact stdout line, d = the detail object"""
+    for x in (c, d):
+        assert x["n_gpus"] == 2 and x["steps"] == 3 and x["warmup"] == 1 and x["scaling"] == "weak"
+        assert x["value"] > 0 and x["value"] == x["value"] and x["value"] != float("inf")
+        # N > 1: the headline is the 64x36 clip (BASELINE configs[3]); whole-job frames / max-rank time
+        assert x["config"]["frames_per_clip"] == 64 and x["config"]["boxes_per_frame"] == 36
+        assert abs(x["value"] - 2 * cps * 64 / (x["ms_per_step"] * 1e-3)) < 1e-6 * x["value"]
+        assert x["allgather_ms"] > 0 and x["allgather_bytes_per_rank"] == cps * 2240 * 26 * 4
+        assert x["ranks_seen"] == 2 and x["distinct_devices"] == 1 and x["one_rank_alone"]["value"] > 0
+        assert "rank(s)" in x["config"]["sharding"] and x["config"]["layout_cache"].startswith("miss every step")
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"]
     assert len(d["repeats"]) == 2 and min(d["repeats"]) <= d["value"] <= max(d["repeats"])
-    assert d["allgather_ms"] > 0 and d["allgather_bytes_per_rank"] == cps * 2240 * 26 * 4
-    assert "scaling_note" in d and "rank(s)" in d["config"]["sharding"]
+    assert "scaling_note" in d
     # what RCCL (here: gloo) saw
-    assert d["ranks_seen"] == 2 and [x["rank"] for x in d["devices"]] == [0, 1]
+    assert [x["rank"] for x in d["devices"]] == [0, 1]
     assert all(x["device"] == 0 and x["pci_bus_id"] for x in d["devices"])         # both ranks forced onto GPU 0 ...
-    assert d["distinct_devices"] == 1 and d["devices"][0]["pid"] != d["devices"][1]["pid"]   # ... as two processes
-    assert d["one_rank_alone"]["value"] > 0
+    assert d["devices"][0]["pid"] != d["devices"][1]["pid"]                        # ... as two processes
     w = d["workloads"]["16x12"]                                    # configs[1]'s clip rides along
     assert w["value"] > 0 and w["config"]["frames_per_clip"] == 16 and w["allgather_ms"] > 0
-    # strong scaling: fixed clip sets sharded over the two ranks, scored on rank 0
+    assert c["workloads"]["16x12"]["value"] > 0
+    # strong scaling: fixed clip sets sharded over the two ranks, every rank scores its own clips, tallies all-reduced
     for key, clips in (("64x36_x64", 6), ("ag_split_shaped", 40)):
         b = d["strong_scaling"][key]
         assert b["clips"] == clips and b["ranks"] == 2 and b["value"] > 0 and b["lpt_imbalance"] >= 1.0
         assert [x["rank"] for x in b["per_rank"]] == [0, 1] and sum(x["clips"] for x in b["per_rank"]) == clips
         assert sum(x["frames"] for x in b["per_rank"]) == b["frames"] and all(x["busy_s"] > 0 for x in b["per_rank"])
+        assert all(x["eval_s"] > 0 and x["gather_mismatch"] == 0 for x in b["per_rank"]) and b["gather_verified"] is True
         assert set(b["recall_with_constraint"]) == {"10", "20", "50"}
+        cb = c["strong_scaling"][key]
+        assert cb["ranks"] == 2 and cb["eval_s_rank0"] > 0 and cb["busy_max_s"] > 0 and cb["gather_verified"] is True
 
 
 SMALL = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--no-roofline", "--clips-per-step", "2",
@@ -68,13 +88,22 @@ def test_bench_self_launches_two_ranks():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, cwd=ROOT, env=dict(env, **GLOO_ON_GPU0),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    _check_two_rank_line(json.loads(lines[0]), 2)
+    c, d = _run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, GLOO_ON_GPU0)
+    _check_two_rank_line(c, d, 2)
+
+
+def test_launcher_counts_gpus_without_the_runtime():
+    """the launcher parent counts devices from sysfs: it must agree with the runtime's count on this box, and bench.py's
+    launcher path must not call the runtime"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.visible_gpu_count() == torch.cuda.device_count()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def launch_ranks("):src.index("def pci_bus_id(")]
+    assert "torch.cuda" not in body
 
 
 def test_bench_self_launch_propagates_a_failing_rank():
@@ -94,24 +123,35 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-              "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + SMALL, GLOO_ON_GPU0)
-    _check_two_rank_line(d, 2)
+    c, d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + SMALL, GLOO_ON_GPU0)
+    _check_two_rank_line(c, d, 2)
 
 
 def test_bench_default_line_shape():
-    """one rank, reduced step counts: the fields the driver and the judge read, incl. the per-kernel roofline rows and
-    the 64x36 block measured in the same run"""
+    """one rank, reduced step counts: the compact line carries every contract field as scalars (< 4 KB); the detail
+    object carries the per-kernel roofline rows and the blocks of the other BASELINE configs measured in the same run"""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--ag-clips", "256",
-              "--strong-clips", "8"])
+    c, d = _run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--ag-clips", "256", "--strong-clips", "8"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "one_clip_per_pass", "workloads", "repeats",
-              "ranks_seen", "devices", "distinct_devices", "strong_scaling"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "one_clip_per_pass", "workloads", "repeats",
+              "ranks_seen", "distinct_devices", "strong_scaling", "same_batch", "pcie_inclusive_overlapped"):
+        assert k in c, k
         assert k in d, k
-    assert d["config"]["frames_per_clip"] == 16 and d["ranks_seen"] == 1 and d["distinct_devices"] == 1
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+    assert c["config"]["frames_per_clip"] == 16 and c["ranks_seen"] == 1 and c["distinct_devices"] == 1
+    assert abs(c["value"] - 64 * 16 / (c["ms_per_step"] * 1e-3)) < 1e-6 * c["value"]
+    assert c["config"]["layout_cache"] == "miss every step" and c["same_batch"]["value"] > 0
+    assert 0 < c["pcie_inclusive_overlapped"]["value"] < c["value"] and c["pcie_inclusive_overlapped"]["h2d_gb_per_s"] > 1
+    assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
+    for name in ("64x36", "dsgdetr_16x12", "ag_split_shaped"):
+        assert c["workloads"][name]["value"] > 0, name
+    assert c["workloads"]["64x36"]["one_clip_per_pass"] > 0 and c["workloads"]["64x36"]["roofline_frac"] > 0
+    dom = c["roofline"]["dominant"]
+    assert "gemm16_kernel" in dom["name"] and 0 < dom["frac"] < 1 and dom["launches_per_step"] >= 1
+    # ---- detail ----
     assert len(d["repeats"]) == 3 and sorted(d["repeats"])[1] == d["value"]
     assert d["roofline"]["traffic_measured_in_run"] is False
     r = d["roofline"]
@@ -125,14 +165,16 @@ def test_bench_default_line_shape():
     assert abs(gf / ms - r["achieved"]) < 1e-6 * r["achieved"]        # GFLOP per ms = TFLOP/s
     w = d["workloads"]["64x36"]
     assert w["value"] > 0 and w["roofline"]["frac"] > 0 and w["roofline"]["by_kernel"] and w["one_clip_per_pass"]["value"] > 0
-    # BASELINE configs[4] (DSG-DETR) and the configs[2] stand-in ride in the same line
+    # BASELINE configs[4] (DSG-DETR) and the configs[2] stand-in ride in the same run
     g = d["workloads"]["dsgdetr_16x12"]
     assert "error" not in g and g["value"] > 0 and g["roofline"]["frac"] > 0
     a = d["workloads"]["ag_split_shaped"]
     assert "error" not in a and a["value"] > 0 and a["clips"] == 256 and a["frames"] > 5000
-    assert a is not None and d["strong_scaling"]["ag_split_shaped"]["clips"] == 256
+    assert d["strong_scaling"]["ag_split_shaped"]["clips"] == 256
     s64 = d["strong_scaling"]["64x36_x64"]
     assert "error" not in s64 and s64["clips"] == 8 and s64["frames"] == 8 * 64 and s64["ranks"] == 1 and s64["lpt_imbalance"] == 1.0
+    assert s64["per_rank"][0]["eval_s"] > 0 and s64["gather_verified"] is False
     # --profile-only-batch: nothing but warm-up + timed steps
-    p = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
+    p, _ = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
     assert "roofline" not in p and "workloads" not in p and "one_clip_per_pass" not in p and "cpu_baseline" not in p
+    assert "pcie_inclusive_overlapped" not in p

@@ -222,3 +222,125 @@ def test_assign_clips_balances_and_is_deterministic():
     assert owner == assign_clips(costs, 4)
     assert assign_clips([], 3) == []
     assert set(assign_clips([1] * 8, 8)) == set(range(8))
+
+
+# ---- world 4: unequal packs per rank, a rank without clips, sharded scoring merged by ONE all-reduce of tallies -----------
+OBJ = ["__background__"] + [f"c{i}" for i in range(36)]
+ATT = [f"att{i}" for i in range(3)]; SPA = [f"spa{i}" for i in range(6)]; CON = [f"con{i}" for i in range(17)]
+
+
+def _scored_clip(i, frames):
+    """clip i of the test set: a synthetic predcls entry with random 'predictions' + its ground truth (a deterministic
+    function of i, so every rank can build any clip)"""
+    import numpy as np
+    from nl_vsgg_amd.lib import synthetic as syn
+    rng = np.random.default_rng([77, i])
+    e = syn.make_entry(1000 + i, rng.integers(1, 5, frames).tolist(), mode="predcls")
+    P = e["pair_idx"].shape[0]
+    pred = {k: e[k] for k in ("pair_idx", "im_idx", "boxes", "labels", "scores")}
+    pred["attention_distribution"] = rng.standard_normal((P, 3)).astype(np.float32)
+    pred["spatial_distribution"] = rng.uniform(0, 1, (P, 6)).astype(np.float32)
+    pred["contacting_distribution"] = rng.uniform(0, 1, (P, 17)).astype(np.float32)
+    return pred, syn.make_gt_annotation_hard(500 + i, e, jitter=6.0)
+
+
+def _evaluator():
+    from nl_vsgg_amd.lib.evaluation_recall import SceneGraphEvaluator
+    ev = SceneGraphEvaluator(mode="predcls", AG_object_classes=OBJ, AG_all_predicates=ATT + SPA + CON,
+                             AG_attention_predicates=ATT, AG_spatial_predicates=SPA, AG_contacting_predicates=CON, iou_threshold=0.5)
+    ev.register_container()
+    return ev
+
+
+FRAMES4 = [9, 2, 7, 3, 3, 5, 2]          # 7 clips over 4 ranks with costs that leave the ranks 1..3 clips; + rank 3 emptied below
+
+
+def _worker_world4(rank, world, port, q):
+    import numpy as np
+    from nl_vsgg_amd.lib.distributed import all_reduce_recall
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        costs = [float(f) * f for f in FRAMES4]
+        owner = assign_clips(costs, world - 1)             # ranks 0..2 own clips, rank 3 owns NONE (an empty rank)
+        lists = [[i for i, o in enumerate(owner) if o == r] for r in range(world)]
+        pack = 2                                           # clips per "forward": unequal numbers of packs per rank
+        packs = [[l[j:j + pack] for j in range(0, len(l), pack)] for l in lists]
+        rounds = max(len(p) for p in packs)
+        clips = {i: _scored_clip(i, FRAMES4[i]) for i in lists[rank]}
+        rows_of = lambda i: int(clips[i][0]["pair_idx"].shape[0])
+        pairs_all = [int(_scored_clip(i, f)[0]["pair_idx"].shape[0]) for i, f in enumerate(FRAMES4)]
+        rows_cap = max(sum(pairs_all[i] for i in pk) for pq in packs for pk in pq)
+        g = PredictionGatherer(rows_cap, pack, cols=26, depth=2)
+        ev = _evaluator()
+        ok = True
+        for r_ in range(rounds):
+            ids = packs[rank][r_] if r_ < len(packs[rank]) else []          # some ranks have run out of packs: empty submit
+            for i in ids:
+                ev.evaluate_scene_graph(clips[i][1], clips[i][0])           # every rank scores ITS OWN clips
+            rows = [torch.from_numpy(np.concatenate([clips[i][0][k] for k in ("attention_distribution", "spatial_distribution",
+                                                                             "contacting_distribution")], 1)) for i in ids]
+            local = torch.cat(rows) if rows else g.payload()[:0]
+            t = g.submit(local, ids, [rows_of(i) for i in ids])
+            buf, rec = g.gathered(t)                                        # the predictions of every rank, on every rank
+            for q_ in range(world):
+                want = packs[q_][r_] if r_ < len(packs[q_]) else []
+                ok = ok and [int(c) for c, _ in rec[q_].tolist() if c >= 0] == want
+                off = 0
+                for i in want:
+                    p, _ = _scored_clip(i, FRAMES4[i])
+                    ok = ok and torch.equal(buf[q_, off:off + pairs_all[i], :3], torch.from_numpy(p["attention_distribution"]))
+                    off += pairs_all[i]
+        g.raise_if_overflowed()
+        merged = all_reduce_recall(ev)                                      # one all-reduce of (sum, count) tallies
+        q.put((rank, bool(ok), merged, [len(p) for p in packs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world4_unequal_packs_empty_rank_and_merged_recall():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_world4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get() for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    npacks = res[0][3]
+    assert npacks[3] == 0 and len(set(npacks[:3])) > 1, npacks           # an empty rank, unequal pack counts elsewhere
+    # the merged table == one evaluator over all clips in one process (the reference's loop), on every rank
+    ev = _evaluator()
+    for i, f in enumerate(FRAMES4):
+        pred, gt = _scored_clip(i, f)
+        ev.evaluate_scene_graph(gt, pred)
+    ev.calculate_mean_recall()
+    want = ev.summary()
+    for _, _, merged, _ in res:
+        for t in want:
+            for k in want[t]:
+                assert merged[t][k] == pytest.approx(want[t][k], abs=1e-12), (t, k)
+    # and the single-process identity: summary_from_partial_sums(partial_sums()) == summary()
+    same = ev.summary_from_partial_sums(ev.partial_sums())
+    assert all(same[t][k] == pytest.approx(want[t][k], abs=1e-12) for t in want for k in want[t])
+
+
+def test_gathered_counts_overflow_records():
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = PredictionGatherer(rows_cap=4, clips_cap=2, cols=26)
+        g.gathered(g.submit(torch.ones(3, 26), [0], [3]))
+        g.raise_if_overflowed()                                             # nothing overflowed: no error
+        g.gathered(g.submit(torch.zeros(5, 26), [0], [5]))                  # does not fit: the raw rows are not predictions
+        with pytest.raises(ValueError):
+            g.raise_if_overflowed()
+        g.raise_if_overflowed()                                             # reported once
+    finally:
+        dist.destroy_process_group()

@@ -45,16 +45,19 @@ for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<
   python3 tools/pmc_mfma_busy.py "$O/${P}_pmc_busy_" "$k" "$C" > "$O/${P}_pmc_mfma_busy_$tag.json"
 done
 # 4. bench lines (unprofiled)
-python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
-python3 bench.py --workload 64x36 --steps 20 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_64x36.json" 2>/dev/null
-python3 bench.py --workload 64x36 --clips-per-step 1 --steps 20 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_64x36_single_clip.json" 2>/dev/null
-python3 bench.py --clips-per-step 1 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_16x12_single_clip.json" 2>/dev/null
-python3 bench.py --clips-per-step 16 --no-cpu-baseline --no-extra-workloads > "$O/${P}_bench_16x12_16clips.json" 2>/dev/null
-python3 bench.py --model dsgdetr --no-cpu-baseline > "$O/${P}_bench_dsgdetr_16x12.json" 2>/dev/null
-python3 bench.py --model dsgdetr --workload 64x36 --steps 10 --no-cpu-baseline > "$O/${P}_bench_dsgdetr_64x36.json" 2>/dev/null
+# (stdout = the one compact line the driver parses; the full object goes to $BENCH_DETAIL)
+BENCH_DETAIL="$O/${P}_bench_default_detail.json" python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
+# the driver's own command
+BENCH_DETAIL="$O/${P}_bench_driver_cmd_detail.json" python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/${P}_bench_driver_cmd.json" 2>/dev/null
+python3 bench.py --workload 64x36 --steps 20 --no-cpu-baseline --no-extra-workloads --detail "$O/${P}_bench_64x36_detail.json" > "$O/${P}_bench_64x36.json" 2>/dev/null
+python3 bench.py --workload 64x36 --clips-per-step 1 --steps 20 --no-cpu-baseline --no-extra-workloads --detail "$O/${P}_bench_64x36_single_clip_detail.json" > "$O/${P}_bench_64x36_single_clip.json" 2>/dev/null
+python3 bench.py --clips-per-step 1 --no-cpu-baseline --no-extra-workloads --detail "$O/${P}_bench_16x12_single_clip_detail.json" > "$O/${P}_bench_16x12_single_clip.json" 2>/dev/null
+python3 bench.py --clips-per-step 16 --no-cpu-baseline --no-extra-workloads --detail "$O/${P}_bench_16x12_16clips_detail.json" > "$O/${P}_bench_16x12_16clips.json" 2>/dev/null
+python3 bench.py --model dsgdetr --no-cpu-baseline --detail "$O/${P}_bench_dsgdetr_16x12_detail.json" > "$O/${P}_bench_dsgdetr_16x12.json" 2>/dev/null
+python3 bench.py --model dsgdetr --workload 64x36 --steps 10 --no-cpu-baseline --detail "$O/${P}_bench_dsgdetr_64x36_detail.json" > "$O/${P}_bench_dsgdetr_64x36.json" 2>/dev/null
 python3 tools/ag_split_bench.py > "$O/${P}_ag_split_shaped.json" 2>/dev/null
 # two ranks on this one GPU over gloo (the N > 1 code path, self-launched): what the 8-GPU driver run will execute
 BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline \
-  > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
+  --detail "$O/${P}_bench_2ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
 ls "$O" | grep "^${P}_" | grep -v "_kt_\|_pmc_[a-z0-9]*_[A-Z]" | head -60
 du -sh "$O"
