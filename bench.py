@@ -149,18 +149,29 @@ def cpu_baseline(T, N, sd, budget_s=24.0, model_kind="sttran", threads=None):
 
 def visible_gpu_count():
     """GPUs this process's children will see, WITHOUT loading a GPU runtime in this process: the KFD topology in sysfs
-    (a node with SIMDs is a GPU), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.
-    None when the topology cannot be read (then the children find out themselves)."""
+    (a readable node with SIMDs is a GPU), else the render nodes in /dev/dri; narrowed by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when neither can be read.  ADVISORY: the launcher only
+    warns on it -- a rank whose device ordinal does not exist fails in `Env` and the launcher propagates its exit code."""
+    n = None
     root = "/sys/class/kfd/kfd/topology/nodes"
-    try:
-        n = 0
+    try:                                       # 1. KFD topology: a node with SIMDs is a GPU; a container sees the nodes of
+        k = 0                                  #    the whole host but can only READ the properties of its own GPUs
         for node in os.listdir(root):
-            with open(os.path.join(root, node, "properties")) as f:
-                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+            except OSError:
+                continue
             if int(props.get("simd_count", "0")) > 0:
-                n += 1
-    except OSError:
-        return None
+                k += 1
+        n = k
+    except (OSError, ValueError):
+        pass
+    if not n:                                  # 2. the render nodes the process was given
+        try:
+            n = len([d for d in os.listdir("/dev/dri") if d.startswith("renderD")])
+        except OSError:
+            return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -175,8 +186,8 @@ def launch_ranks(n, argv):
     return the first non-zero exit code (the remaining children are then terminated by their own PIDs) or 0."""
     ndev = visible_gpu_count()
     if ndev is not None and ndev < n and "BENCH_FORCE_DEVICE" not in os.environ:
-        print(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible", file=sys.stderr)
-        return 2
+        print(f"bench.py: --gpus {n} but sysfs shows {ndev} GPU(s); starting the ranks anyway (each checks its own device)",
+              file=sys.stderr)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -376,6 +387,10 @@ class Env:
         # one process per GPU; BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only so the N>1 code path can be
         # smoke-tested on a single-GPU box (all ranks on device 0, gloo instead of RCCL): tests/test_bench_gpu.py
         self.local = int(os.environ.get("BENCH_FORCE_DEVICE", local))
+        if self.local >= torch.cuda.device_count():
+            print(f"bench.py: rank {self.rank}: device ordinal {self.local} does not exist ({torch.cuda.device_count()} GPU(s) "
+                  f"visible)", file=sys.stderr)
+            raise SystemExit(2)
         torch.cuda.set_device(self.local)
         self.device = torch.device("cuda", self.local)
         self.dist = None

@@ -47,6 +47,9 @@ struct GemmOperand {
   // operand then live in several allocations, `ptr` is the first clip's tensor and an offset may be any signed
   // distance inside the device's address space (pair_prep_kernel writes them).  Takes precedence over rowidx.
   const int64_t* rowoff;
+  // rowidx operands: number of physical rows rowidx may address (0 = unknown).  gemm16_kernel (gemm_f32_t16.h) addresses
+  // a GATHERED operand by 32-bit byte offsets from `ptr`: gemm_linear takes it only when span * ld * 4 < 4 GB is known.
+  int64_t span;
 };
 
 // B-operand kinds.  B_KMAJOR: rows of W[N][K], K-contiguous (nn.Linear weights, im2col rows).

@@ -113,20 +113,23 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
     if constexpr (ABL == 9) clk0 = __builtin_readcyclecounter();
 #endif
 
-    // global source of every staged piece, as a 32-bit BYTE offset from the operand's base (the launcher guarantees the
-    // operands span less than 4 GB; a uniform base + 32-bit lane offset is one VGPR per piece instead of two).  Rows past M
-    // read row 0 of the operand: never stored by the epilogue.
+    // global source of every staged piece: a uniform 64-bit base per TILE (the tile's first row of A / of W) plus a 32-bit
+    // BYTE offset per lane -- one VGPR per piece instead of two, and no limit on the operand's size: an in-tile offset is
+    // < (BM + 1) * ld * 4.  A GATHERED A operand (rowidx) has no tile-local base: its offsets are taken from A.ptr, and
+    // gemm_linear only sends it here when its span is known to stay below 4 GB (GemmOperand::span).  Rows past M read
+    // the tile's first row (gathered: row 0 of the operand): never stored by the epilogue.
     uint32_t oa[AV], ob[BV];
+    const bool gathered = A.rowidx != nullptr;
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + srow + RPR * i;
-      const int64_t prow = g < M ? (A.rowidx ? A.rowidx[g] : g) : 0;
+      const int64_t prow = g < M ? (gathered ? (int64_t)A.rowidx[g] : (int64_t)(g - m0)) : 0;
       oa[i] = (uint32_t)((prow * A.ld + schunk * 4 + ks0 * kBK) * 4);
     }
 #pragma unroll
-    for (int i = 0; i < BV; ++i) ob[i] = (uint32_t)(((int64_t)(n0 + brow(i)) * B.ld + schunk * 4 + ks0 * kBK) * 4);
-    const char* const abase = reinterpret_cast<const char*>(A.ptr);
-    const char* const bbase = reinterpret_cast<const char*>(B.ptr);
+    for (int i = 0; i < BV; ++i) ob[i] = (uint32_t)(((int64_t)brow(i) * B.ld + schunk * 4 + ks0 * kBK) * 4);
+    const char* const abase = reinterpret_cast<const char*>(A.ptr) + (gathered ? (int64_t)0 : (int64_t)m0 * A.ld * 4);
+    const char* const bbase = reinterpret_cast<const char*>(B.ptr) + (int64_t)n0 * B.ld * 4;
     // two register sets: the global loads of K-step u go to set u & 1, TWO steps ahead of their use (issued during step
     // u - 2, written to LDS during step u - 1), so a load has more than a whole K-step (~5 us) to arrive from HBM
     f32x4 ra[2][AV], rb[2][BV];

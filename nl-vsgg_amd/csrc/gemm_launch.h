@@ -16,7 +16,7 @@ struct TileInfo { int bm, bn; float eff; int blocks_per_cu; };
 static const TileInfo kTiles[TILE_COUNT] = {
     {0, 0, 0.f, 0}, {256, 128, 0.90f, 1}, {128, 128, 0.88f, 2}, {64, 64, 0.79f, 4}, {128, 64, 0.85f, 2},
     {128, 176, 0.93f, 2},    // gemm_f32_t16.h: 76 KB of LDS, two workgroups of 4 waves per CU
-    {256, 176, 0.93f, 1},    // ... 108 KB of LDS, one workgroup of 8 waves
+    {0, 0, 0.f, 0},          // (id 6 retired: the 256 x 176 form)
     {128, 128, 0.92f, 2}};   // ... 64 KB of LDS, N % 128 == 0 (2048, 512)
 
 // Hybrid data-parallel + stream-K schedule of one GEMM: G persistent workgroups each run dp_per_wg whole

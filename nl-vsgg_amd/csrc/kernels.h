@@ -33,7 +33,8 @@ int num_cus();   // compute units of the current device (cached per ordinal)
 // ---- GEMM ------------------------------------------------------------------------------
 // tiles of gemm_f32_mfma.h (ids are part of the sttran_debug_gemm test hook: keep them stable)
 // 5: gemm_f32_t16.h (16x16x4 MFMA blocks; N % 176 == 0, padded operands, vector epilogue only)
-enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_128x176 = 5, TILE_256x176 = 6,
+// 6 was a 256 x 176 form of the 16x16x4 family (never faster than 128 x 176, 66 spilled VGPRs): removed in round 4, id retired
+enum { TILE_AUTO = 0, TILE_256x128 = 1, TILE_128x128 = 2, TILE_64x64 = 3, TILE_128x64 = 4, TILE_128x176 = 5, TILE_RETIRED_6 = 6,
        TILE_T128x128 = 7, TILE_COUNT = 8 };
 struct GemmPlan { int tile; int splitk; };
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split);

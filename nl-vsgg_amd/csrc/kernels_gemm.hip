@@ -33,14 +33,14 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_sp
   const int64_t ksteps = (K + kBK - 1) / kBK;
   static const int env_tile = getenv("STTRAN_GEMM_TILE") ? atoi(getenv("STTRAN_GEMM_TILE")) : 0;   // experiments only
   if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT) force_tile = env_tile;
-  if (force_tile < 0 || force_tile >= TILE_COUNT) force_tile = 0;
+  if (force_tile < 0 || force_tile >= TILE_COUNT || force_tile == TILE_RETIRED_6) force_tile = 0;
   for (int t = 1; t < TILE_COUNT; ++t) {
     if (force_tile && t != force_tile) continue;
     // the 176-column tile only serves N = 11 k x 16 exactly (1936 / 3872 / 5808); gemm_linear falls back to 256 x 128
     // when the operands / epilogue do not meet its contract
-    if ((t == TILE_128x176 || t == TILE_256x176) && (N % 176 != 0 || (!force_tile && M < kT16MinRows))) continue;
+    if (t == TILE_RETIRED_6) continue;
+    if (t == TILE_128x176 && (N % 176 != 0 || (!force_tile && M < kT16MinRows))) continue;
     if (t == TILE_T128x128 && (N % 128 != 0 || (!force_tile && M < kT16MinRows))) continue;
-    if (t == TILE_256x176 && !force_tile) continue;     // measured equal or slower than 128 x 176 at every shape of the path: by request only
     const TileInfo& ti = kTiles[t];
     const int64_t tm = (M + ti.bm - 1) / ti.bm, tn = (N + ti.bn - 1) / ti.bn, tiles = tm * tn;
     const int G = grid_of(t, tiles, ksteps);
@@ -69,7 +69,7 @@ size_t gemm_slab_floats_max() {
   const int dev = current_device();
   if (!cached[dev]) {
     size_t m = 0;
-    for (int t = 1; t < TILE_COUNT; ++t) m = std::max(m, gemm_slab_floats(GemmPlan{t, 1}, 0, 0));
+    for (int t = 1; t < TILE_COUNT; ++t) if (t != TILE_RETIRED_6) m = std::max(m, gemm_slab_floats(GemmPlan{t, 1}, 0, 0));
     cached[dev] = (m + 63) & ~size_t(63);
   }
   return cached[dev];
@@ -91,9 +91,15 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
   if (M <= 0 || N <= 0) return hipSuccess;
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
-  if (plan.tile == TILE_128x176 || plan.tile == TILE_256x176 || plan.tile == TILE_T128x128) {
+  if (plan.tile == TILE_128x176 || plan.tile == TILE_T128x128) {
+    // gemm16_kernel addresses by (64-bit tile base + 32-bit in-tile byte offset): any operand size, as long as one tile's
+    // rows stay inside 4 GB (ld < 2^21 floats); a GATHERED A has no tile base -- its rows must be known to lie within 4 GB
+    // of A.ptr (GemmOperand::span; unknown = the general engine, which carries 64-bit pointers)
+    const int64_t kLim = (int64_t)1 << 32;
+    const bool a_ok = A.rowidx ? (A.span > 0 && (A.span * A.ld + ((K + 31) / 32) * 32) * 4 < kLim) : (129 * A.ld * 4 < kLim);
+    const bool b_ok = !B.rowidx && !B.rowoff && 177 * B.ld * 4 < kLim;
     if (padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff && aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) &&
-        (B.ld & 3) == 0)
+        (B.ld & 3) == 0 && a_ok && b_ok)
       return gemm_linear_t16(s, A, B, M, N, K, epi, slab, plan.tile);
     plan.tile = TILE_256x128;                          // contract not met: the general engine
   }

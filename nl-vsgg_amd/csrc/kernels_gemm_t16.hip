@@ -70,7 +70,6 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
 
 hipError_t gemm_linear_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                            const EpiLinear& epi, float* slab, int tile) {
-  if (tile == TILE_256x176) return launch_t16<Tile16<256, 176>, TILE_256x176>(s, A, B, M, N, K, epi, slab);
   if (tile == TILE_T128x128) return launch_t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, epi, slab);
   return launch_t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, epi, slab);
 }

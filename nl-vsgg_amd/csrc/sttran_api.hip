@@ -257,7 +257,6 @@ const char* tile_name(int tile) {
     case TILE_128x64: return "128,64,2,2";
     case TILE_64x64: return "64,64,2,2";
     case TILE_128x176: return "128,176";
-    case TILE_256x176: return "256,176";
     case TILE_T128x128: return "128,128";
     default: return "?";
   }
@@ -326,7 +325,7 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     }
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
-  const bool t16 = plan.tile == TILE_128x176 || plan.tile == TILE_256x176 || plan.tile == TILE_T128x128;
+  const bool t16 = plan.tile == TILE_128x176 || plan.tile == TILE_T128x128;
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
                t16 ? std::string("gemm16_kernel<Tile16<") + tile_name(plan.tile) + ">,EpiLinear>"
                    : std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
@@ -1222,7 +1221,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
         EpiLinear eq = epi_plain(QKV, 3 * D, bin);                          // q columns, needed rows only
         eq.rowbias = h->dec[i].posbias; eq.rowslot = slot; eq.rb_cols = D; eq.rb_ld = 2 * D;
         eq.out_rowidx = need;
-        if ((rc = run_linear(h, s, GemmOperand{G, LD, need}, Win, NN, D, D, eq))) return rc;
+        if ((rc = run_linear(h, s, GemmOperand{G, LD, need, 0, nullptr, NT}, Win, NN, D, D, eq))) return rc;
       }
       {
         ProfScope ps(h, s, STTRAN_PROF_ATTENTION, 4.0 * MQ * L.max_dec * D, 4.0 * (MQ * 2.0 + NT * 2.0) * D, "attention", MQ,
@@ -1233,7 +1232,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
       EpiLinear eo = epi_plain(Y, LD, W(h, p + ".multihead2.out_proj.bias"));
       eo.res = G; eo.ldres = LD; eo.res_rowidx = rows;
       if (i == 0 && !need_g0) { eo.res = UNI; eo.res_rowidx = dec_src; }      // residual = the window token's encoder row
-      if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
+      if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows, 0, nullptr, NT}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
       {
         ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D, "layernorm_kernel", MQ, D, 0);
         HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, LD, MQ, D));
@@ -1380,8 +1379,18 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
     return STTRAN_ERR_HIP;
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
-  hipError_t err = gemm_linear(s, GemmOperand{A, lda, a_rowidx}, GemmOperand{Wt, ldw, nullptr}, (int)M, (int)N, (int)K,
-                               e, plan, slab, 1);
+  // a gathered operand's span (GemmOperand::span) is what the forward knows from its buffers; a test hook reads the index
+  // back (one synchronisation) so that the 16x16x4 tiles can be exercised with gathered rows
+  int64_t span = 0;
+  if (a_rowidx) {
+    std::vector<int32_t> idx((size_t)M);
+    if (hipMemcpyAsync(idx.data(), a_rowidx, (size_t)M * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return STTRAN_ERR_HIP;
+    for (int32_t v : idx) { if (v < 0) return STTRAN_ERR_INVALID; span = std::max<int64_t>(span, (int64_t)v + 1); }
+  }
+  hipError_t err = gemm_linear(s, GemmOperand{A, lda, a_rowidx, 0, nullptr, span}, GemmOperand{Wt, ldw, nullptr}, (int)M, (int)N,
+                               (int)K, e, plan, slab, 1);
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 

@@ -275,11 +275,11 @@ class SceneGraphEvaluator:
         for t in ("recall", "recall_nogc", "semi_recall"):
             for k in KS:
                 v = rd[f"{m}_{t}"][k]
-                out += [float(np.sum(v, dtype=np.float64)) if len(v) else 0.0, float(len(v))]
+                out += [float(sum(v)), float(len(v))]        # (the builtin: these are Python lists of floats, 10^4..10^5 long)
         for t in ("mean_recall", "ng_mean_recall"):
             for k in KS:
                 for v in rd[f"{m}_{t}_collect"][k]:
-                    out += [float(np.sum(v, dtype=np.float64)) if len(v) else 0.0, float(len(v))]
+                    out += [float(sum(v)), float(len(v))]
         return np.asarray(out, dtype=np.float64)
 
     def summary_from_partial_sums(self, vec):

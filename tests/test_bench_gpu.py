@@ -111,7 +111,8 @@ def test_bench_self_launch_propagates_a_failing_rank():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    # more ranks than GPUs and nothing forcing them onto one device: refused before any child starts
+    # more ranks than GPUs and nothing forcing them onto one device: the rank without a device exits with code 2 before
+    # any collective, the launcher stops the others and propagates the code
     env.pop("BENCH_FORCE_DEVICE", None)
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + SMALL, cwd=ROOT, env=env, capture_output=True,

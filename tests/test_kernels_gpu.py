@@ -87,7 +87,7 @@ def test_gemm_padded_path(lib, M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K", [(2816, 1936, 1936), (5280, 1936, 2048), (330, 5808, 1936), (700, 3872, 1936), (1, 176, 32),
                                    (129, 352, 100), (21120, 1936, 1936)])
-@pytest.mark.parametrize("tile", [5, 6])
+@pytest.mark.parametrize("tile", [5])
 def test_gemm_tile_128x176(lib, M, N, K, tile):
     """the 16x16x4-MFMA tile of the N = 1936 family (gemm_f32_t16.h): exact in N, two workgroups per CU, XOR-swizzled LDS;
     bias + ReLU + residual through the 16-byte epilogue, stream-K remainders through its own fix-up kernel"""
@@ -112,7 +112,7 @@ def test_gemm_tile_128x176(lib, M, N, K, tile):
     assert torch.equal(Cc, C2)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
 def test_gemm_padded_path_gathered_rows(lib, tile):
     """A rows gathered through an index (subj/obj FC, last-decoder-layer row pruning), every tile"""
     g = torch.Generator(device="cuda").manual_seed(40 + tile)
@@ -489,3 +489,42 @@ def test_attention_over_device_side_lengths(lib, lens, bound):
     ref = _attn_ref(qkv, [int(offs[i]) for i in keep], [lens[i] for i in keep], dim, nhead)
     assert torch.isfinite(out).all()
     assert (out.double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemm_t16_operand_larger_than_4_gb(lib):
+    """gemm16_kernel stages through 32-bit byte offsets.  They are taken from a 64-bit base per TILE now, so an
+    activation operand of more than 4 GB (550 k rows at the workspace's row stride of 1952 floats: decoder tokens of
+    ~275 k pairs, which 288 GB hold) is read where it is -- and a GATHERED operand, whose offsets are taken from the
+    operand's base, only reaches the kernel when its span is known to stay below 4 GB (else the general engine, which
+    carries 64-bit pointers, serves it).  Both cases: rows on either side of the 4 GB mark against an fp64 reference."""
+    K, N, ld = 1936, 176, 1952
+    M = (1 << 32) // (ld * 4) + 3000                   # ~553 k rows: the operand ends ~23 MB past 4 GB
+    g = torch.Generator(device="cuda").manual_seed(5)
+    A = torch.zeros(M, ld, device="cuda")
+    probe = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 3000, M)]).cuda()
+    A[probe, :K] = torch.randn(len(probe), K, device="cuda", generator=g)
+    W = torch.zeros(N, ld, device="cuda")
+    W[:, :K] = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g)
+    Cc = torch.full((M, N), float("nan"), device="cuda")
+    assert lib.sttran_debug_plan_tile(M, N, K) == 5
+    assert lib.sttran_debug_gemm_padded(_p(A), ld, None, _p(W), ld, _p(b), None, _p(Cc), M, N, K, 0, 5, None) == 0
+    torch.cuda.synchronize()
+    ref = A[probe, :K].double() @ W[:, :K].double().T + b.double()
+    assert (Cc[probe].double() - ref).abs().max().item() < 2e-4
+    assert torch.isfinite(Cc).all() and (Cc[1000] == b).all()              # an all-zero row: exactly the bias
+    # gathered rows from beyond the 4 GB mark (tile 5 requested: the dispatcher must not wrap)
+    idx = probe.flip(0).to(torch.int32).contiguous()
+    C2 = torch.full((len(idx), N), float("nan"), device="cuda")
+    assert lib.sttran_debug_gemm_padded(_p(A), ld, _p(idx), _p(W), ld, _p(b), None, _p(C2), len(idx), N, K, 0, 5, None) == 0
+    torch.cuda.synchronize()
+    assert (C2.double() - ref.flip(0)).abs().max().item() < 2e-4
+    # ... and gathered rows of a small operand still run on the 16x16x4 tile, bit-identical to the ungathered launch
+    small = A[probe].contiguous()
+    ident = torch.arange(len(probe), device="cuda", dtype=torch.int32)
+    C3, C4 = torch.empty(len(probe), N, device="cuda"), torch.empty(len(probe), N, device="cuda")
+    assert lib.sttran_debug_gemm_padded(_p(small), ld, None, _p(W), ld, _p(b), None, _p(C3), len(probe), N, K, 0, 5, None) == 0
+    assert lib.sttran_debug_gemm_padded(_p(small), ld, _p(ident), _p(W), ld, _p(b), None, _p(C4), len(probe), N, K, 0, 5, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(C3, C4)                         # same launch geometry: the gathered read changes nothing
+    assert (C3 - Cc[probe]).abs().max().item() < 1e-4  # (another M = another stream-K cut of the K sum: close, not identical)

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nl_vsgg_amd import _native  # noqa: E402
 
-TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64", 5: "128x176", 6: "256x176", 7: "T128x128"}
+TILES = {1: "256x128", 2: "128x128", 3: "64x64", 4: "128x64", 5: "128x176", 7: "T128x128"}
 
 
 def path_shapes(P, NT):
