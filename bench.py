@@ -69,6 +69,7 @@ BF16X3_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS / 6    # the bf16x3 emulation's 
 # 16x12 rate goes 15.8 k (1 clip) -> 28.3 k (8) -> 30.2 k (16) -> 31.3 k (32) -> 32.0 k (64) -> 32.5 k (128) frames/s as
 # tile quantisation and the stream-K fix-ups amortise; `batch_sweep` in the line re-measures 1 / 16 / default every run.
 SHAPES = {"16x12": (16, 12, 64), "64x36": (64, 36, 4)}
+ONE_CLIP_LANES = 4                                              # calls in flight in the one-clip-per-pass leg
 SWEEP_CPS = {"16x12": 16, "64x36": 1}                           # the smaller batch of `batch_sweep` (round 1-2 defaults)
 
 
@@ -614,22 +615,46 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
     # ---- the same clip shape, ONE clip per pass (the reference's own batch size; not `value`) -------------
     if one_clip and cps > 1 and world == 1:
         # two clips alternate (clip 0 of each batch: other tensors, other per-frame counts): every call is a new entry, as
-        # in the reference's loop
+        # in the reference's loop.  (a) `serial`: `model(entry)` on the caller's stream, one clip at a time -- rounds 1-3's
+        # figure; (b) LANES: the same calls as `model.forward_async(entry)` with 4 lanes in the handle -- call i runs on lane
+        # i % 4's own stream, its result is joined (event wait, no host synchronisation) three calls later, as a pipelined
+        # consumer would: one call's launch ramps / prologues / epilogues run under the other calls' MFMAs.
+        import collections
         ones = [b[0] for b in batches]
-        for _ in range(4):
-            for one in ones:
-                model(dict(one))
-        torch.cuda.synchronize()
         n1 = 2 * max(steps, 10)
-        t0 = time.perf_counter()
-        for i in range(n1):
-            model(dict(ones[i % len(ones)]))
-        torch.cuda.synchronize()
-        dt1 = (time.perf_counter() - t0) / n1
-        res["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1, "calls": n1,
+
+        def loop_serial(n):
+            for i in range(n):
+                model(dict(ones[i % len(ones)]))
+
+        def loop_lanes(n):
+            pending = collections.deque()
+            for i in range(n):
+                pending.append(model.forward_async(dict(ones[i % len(ones)])))
+                if len(pending) == model.lanes:
+                    model.join(pending.popleft())
+            while pending:
+                model.join(pending.popleft())
+
+        def timed(fn, n):
+            fn(8)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(n)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        dt_serial = timed(loop_serial, n1)
+        model.lanes = ONE_CLIP_LANES
+        model.reserve(int(ones[0]["pair_idx"].shape[0]) + 8, int(ones[0]["features"].shape[0]) + 8)
+        dt1 = timed(loop_lanes, 2 * n1)
+        model.sync_check()
+        model.lanes = 1
+        res["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1, "calls": 2 * n1,
+                                    "lanes": ONE_CLIP_LANES, "serial": {"value": T / dt_serial, "ms_per_step": 1e3 * dt_serial},
                                     "note": "same clip shape with clips_per_step = 1: the reference's batch "
-                                            "(dataloader/wk_action_genome.py:622-627), a different entry on every call; "
-                                            "latency-bound, one clip cannot fill 256 CUs"}
+                                            "(dataloader/wk_action_genome.py:622-627), a different entry on every call, "
+                                            f"{ONE_CLIP_LANES} calls in flight on the handle's lanes (forward_async / join); "
+                                            "`serial` = one call at a time on the caller's stream"}
 
     # ---- the batch size between one clip and the default (the default of rounds 1-2): a few steps, not `value` ---
     if one_clip and world == 1 and cps > SWEEP_CPS[workload] > 1:
@@ -825,6 +850,9 @@ def compact_line(d):
     for k in ("one_clip_per_pass", "same_batch", "pcie_inclusive_overlapped", "one_rank_alone"):
         if k in d:
             out[k] = {"value": _r(d[k]["value"], 1), "ms_per_step": _r(d[k]["ms_per_step"], 4)}
+    if "one_clip_per_pass" in d and "serial" in d["one_clip_per_pass"]:
+        out["one_clip_per_pass"]["lanes"] = d["one_clip_per_pass"]["lanes"]
+        out["one_clip_per_pass"]["serial"] = _r(d["one_clip_per_pass"]["serial"]["value"], 1)
     if "pcie_inclusive_overlapped" in d:
         out["pcie_inclusive_overlapped"]["h2d_gb_per_s"] = _r(d["pcie_inclusive_overlapped"]["h2d_gb_per_s"], 1)
     if "allgather_ms" in d:
@@ -847,6 +875,8 @@ def compact_line(d):
             e["cpu_baseline"] = _r(blk["cpu_baseline"]["value"], 1)
         if "one_clip_per_pass" in blk:
             e["one_clip_per_pass"] = _r(blk["one_clip_per_pass"]["value"], 1)
+            if "serial" in blk["one_clip_per_pass"]:
+                e["one_clip_serial"] = _r(blk["one_clip_per_pass"]["serial"]["value"], 1)
         if "max_abs_diff_vs_fp32_engine" in blk:
             e["max_abs_diff_vs_fp32_engine"] = blk["max_abs_diff_vs_fp32_engine"]
         if "allgather_ms" in blk:

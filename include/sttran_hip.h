@@ -6,7 +6,9 @@
  * the boundary a drop-in replacement introduces *under* that call; every entry point cites the
  * reference code it stands in for.  Plain pointers and sizes only -- no torch types.
  *
- * Threading: one handle per process/GPU; calls on one handle must be serialised by the caller.
+ * Threading: one handle per process/GPU; calls on one handle must be serialised by the caller (on the host; a forward on
+ * another stream than the handle's previous one is ordered behind it on the device by the library).
+ * Kernel-level test hooks and the experimental GEMM-engine switch are NOT part of this boundary: sttran_hip_debug.h.
  * sttran_forward only enqueues work on the supplied stream (no host synchronisation) when the
  * caller passes `frame_counts`; otherwise it reads `im_idx` back once (the reference itself
  * synchronises twice per frame, lib/transformer.py:138-140).
@@ -160,22 +162,33 @@ int sttran_load_tensor(SttranHandle* h, const char* key, const void* data, const
 int sttran_finalize_weights(SttranHandle* h);
 /* Writes a '\n'-separated list of still-missing state-dict keys into buf; returns their count. */
 int sttran_missing_keys(SttranHandle* h, char* buf, int64_t buflen);
-/* GEMM engine of the nn.Linear layers and the two convolutions (no reference counterpart).  STTRAN_GEMM_FP32_MFMA (default): exact fp32 on
- * v_mfma_f32_32x32x2_f32.  STTRAN_GEMM_BF16X3 (EXPERIMENT, opt-in): fp32 EMULATED on the bf16 matrix pipe -- every
- * operand split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32
- * accumulation (csrc/gemm_bf16x3.h); measured error against fp64 no larger than the exact engine's.  The weights are
- * split once (at the next forward); activations are split on the fly.  Attention, the 7x7 mask convolution and the
- * small GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
-/* STTRAN_GEMM_BF16X3_ALL: the emulated engine for EVERY contraction it can take (N >= 128), whatever the row count -- the
- * form the parity tests use so that small fixtures exercise it too (BF16X3 keeps launches under 512 rows on the exact engine,
- * where the 256-row emulation tile would mostly compute padding). */
-enum { STTRAN_GEMM_FP32_MFMA = 0, STTRAN_GEMM_BF16X3 = 1, STTRAN_GEMM_BF16X3_ALL = 2 };
-int sttran_set_gemm_engine(SttranHandle* h, int32_t engine);
 /* Pre-size the workspace (otherwise grown on demand by forward; growth synchronises). */
 int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes);
 /* `pred = model(entry)` under torch.no_grad(), tools/test_STTran.py:84 ->
  * STTran.forward lib/sttran.py:375-411.  `stream` is a hipStream_t (NULL = default stream). */
 int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs* out, void* stream);
+/* LANES (no reference counterpart): the reference's loop forwards ONE clip per call (tools/test_STTran.py:81-84,
+ * dataloader/wk_action_genome.py:622-627), and one 176-pair clip cannot fill 256 CUs: every launch's ramp / prologue /
+ * epilogue runs with the matrix pipes idle.  A handle can own up to STTRAN_MAX_LANES lanes: each lane has its own
+ * workspace, stream-K park space, index staging and HIP stream (the weights are shared), so consecutive calls on
+ * different lanes overlap on the device and one call's fixed costs hide under another call's MFMAs.
+ *   sttran_set_lanes(h, n)            n lanes (synchronises the device; the default is 1)
+ *   sttran_forward_lane(h, l, in, out, stream)
+ *                                      the forward of sttran_forward on lane l's OWN stream, forked from `stream` with an
+ *                                      event (everything enqueued on `stream` so far -- the producer of the entry --
+ *                                      precedes it); `stream` does NOT wait for the result
+ *   sttran_lane_join(h, l, stream)    `stream` waits for lane l's last forward (l = -1: for every lane's): the consumer
+ *                                      of the outputs calls it first; sttran_sync_check joins all lanes itself
+ *   sttran_lane_stream(h, l, &s)      lane l's hipStream_t (a framework allocator that frees per-stream needs it)
+ * Results are bit-identical to sttran_forward's.  Calls on one handle stay serialised on the HOST by the caller; a lane
+ * is reused only by a later call on the same lane, which its stream orders behind the earlier one.  Inputs and outputs
+ * of a lane call must stay alive until that lane has been joined. */
+#define STTRAN_MAX_LANES 8
+int sttran_set_lanes(SttranHandle* h, int32_t lanes);
+int32_t sttran_num_lanes(SttranHandle* h);
+int sttran_forward_lane(SttranHandle* h, int32_t lane, const SttranInputs* in, const SttranOutputs* out, void* stream);
+int sttran_lane_join(SttranHandle* h, int32_t lane, void* stream);
+int sttran_lane_stream(SttranHandle* h, int32_t lane, void** stream);
 /* Waits for `stream` and reports index errors the kernels met (pair_idx / labels out of range:
  * torch would raise an IndexError at lib/sttran.py:381-393; the kernels clamp and flag). */
 int sttran_sync_check(SttranHandle* h, void* stream);
@@ -304,58 +317,6 @@ typedef struct SttranProfEntry {
   double flops;         /* summed algorithmic FLOPs                                              */
 } SttranProfEntry;
 int sttran_profile_entries(SttranHandle* h, SttranProfEntry* out, int32_t cap, int32_t* count);
-
-/* Kernel-level test hooks: each runs ONE kernel class on caller-provided device buffers so the
- * parity tests can check kernels in isolation (tests/test_kernels_gpu.py). */
-/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+ residual); tile_cfg 0 = auto, split_k 0 = auto. */
-int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* W, const float* bias,
-                      const float* residual, float* C, int64_t M, int64_t N, int64_t K,
-                      int32_t relu, int32_t tile_cfg, int32_t split_k, void* stream);
-/* The product's GEMM path (select-free, two-deep prefetch): A rows `lda` and W rows `ldw` floats apart, both readable
- * (finite) up to the next multiple of 32 columns past K, and W zero there -- how the library stores every nn.Linear
- * weight and lays out its workspace (csrc/gemm_f32_mfma.h, B_KMAJOR_PAD). */
-int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
-                             const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
-                             int32_t relu, int32_t tile_cfg, void* stream);
-/* EXPERIMENT (not on the product's default path): the same GEMM with fp32 EMULATED on the bf16 matrix pipe -- operands
- * split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation
- * (csrc/gemm_bf16x3.h).  W [N,K] fp32 (row stride ldw) is split into planes inside every call; with
- * STTRAN_X3_CACHE_PLANES=1 in the environment the planes of the last W pointer are reused (timing runs). */
-int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
-                         const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
-                         int32_t relu, void* stream);
-/* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
-int sttran_debug_mfma_peak(int32_t iters, double* tflops);
-/* Test allocator: `bytes` of device memory (16-byte aligned) that END at the end of a mapping; the address range behind
- * it is reserved and unmapped, so an access past the buffer is a GPU memory fault, not a silent read of a neighbour.
- * `cookie` goes to sttran_debug_guarded_free.  STTRAN_ERR_HIP if the driver has no virtual-memory API. */
-int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie);
-int sttran_debug_guarded_free(void* cookie);
-/* The tile id (1..8, see csrc/kernels.h) the planner picks for an [M,N,K] nn.Linear GEMM on the current device. */
-int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K);
-/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */
-int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y,
-                           int64_t rows, int64_t dim, void* stream);
-/* Multi-head attention core on packed qkv [tokens, 3*dim] over sequences given by
- * (seq_off, seq_len) device arrays; out [tokens, dim].  nn.MultiheadAttention semantics
- * (q scaled by 1/sqrt(dim/nhead), softmax over the keys of the same sequence). */
-int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32_t* seq_len,
-                           int32_t num_seq, int32_t max_len, float* out, int64_t tokens,
-                           int32_t dim, int32_t nhead, void* stream);
-
-/* DSG-DETR class sequences as the forward builds them on the device (lib/dsg_detr.py:545-555; csrc/kernels_front.hip
- * dsg_layout_kernel): clip_start [num_clips + 1] = pair range of every clip; outputs dec_off / dec_len
- * [num_clips * num_classes] (slot = clip * num_classes + class), dec_src (token -> pair), need (token -> position index,
- * handed out by position like the reference), out_src (pair -> num_pairs + token), each [num_pairs]; scratch4p
- * [4 * num_pairs] ints; err_flag: bit 0 = index out of range, bit 1 = position index >= pe_rows.  All device pointers. */
-int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int64_t num_boxes, const int32_t* clip_start,
-                            int32_t num_clips, int32_t num_classes, int64_t num_pairs, int32_t pe_rows, int32_t* dec_off,
-                            int32_t* dec_len, int32_t* dec_src, int32_t* need, int32_t* out_src, int32_t* scratch4p,
-                            int32_t* err_flag, void* stream);
-/* sttran_debug_attention for sequences whose lengths only the device knows: len_bound >= every seq_len[i]; one launch per
- * length class ((0,48], (48,80], (80,len_bound]), empty slots allowed. */
-int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
-                                   int32_t len_bound, float* out, int32_t dim, int32_t nhead, void* stream);
 
 #ifdef __cplusplus
 }

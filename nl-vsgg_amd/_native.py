@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsttran_hip.so")
 
 STTRAN_OK = 0
+STTRAN_ERR_INVALID = 1
 ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "WEIGHTS", 5: "ORDER", 6: "LIMIT", 7: "INDEX"}
 MODE = {"predcls": 0, "sgcls": 1, "sgdet": 2}
 MODEL_STTRAN, MODEL_DSG_DETR = 0, 1
@@ -91,7 +92,8 @@ class SttranObjclsSelect(C.Structure):
                 ("out_human_idx", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
 
 
-# every symbol include/sttran_hip.h declares: (name, restype, argtypes)
+# every symbol include/sttran_hip.h (the drop-in boundary) and include/sttran_hip_debug.h (test hooks, experiment
+# switches: names `sttran_debug_*` and sttran_set_gemm_engine) declare: (name, restype, argtypes)
 SYMBOLS = [
     ("sttran_create", C.c_int, [C.POINTER(SttranConfig), C.POINTER(C.c_void_p)]),
     ("sttran_load_tensor", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64),
@@ -101,6 +103,11 @@ SYMBOLS = [
     ("sttran_reserve", C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     ("sttran_set_gemm_engine", C.c_int, [C.c_void_p, C.c_int32]),
     ("sttran_forward", C.c_int, [C.c_void_p, C.POINTER(SttranInputs), C.POINTER(SttranOutputs), C.c_void_p]),
+    ("sttran_set_lanes", C.c_int, [C.c_void_p, C.c_int32]),
+    ("sttran_num_lanes", C.c_int32, [C.c_void_p]),
+    ("sttran_forward_lane", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(SttranInputs), C.POINTER(SttranOutputs), C.c_void_p]),
+    ("sttran_lane_join", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    ("sttran_lane_stream", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     ("sttran_sync_check", C.c_int, [C.c_void_p, C.c_void_p]),
     ("sttran_destroy", None, [C.c_void_p]),
     ("sttran_last_error", C.c_char_p, [C.c_void_p]),

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/sttran_hip.h"
+#include "../../include/sttran_hip_debug.h"
 #include "kernels.h"
 
 using namespace sttran;
@@ -102,21 +103,12 @@ struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
 
 }  // namespace
 
-struct SttranHandle {
-  SttranConfig cfg{};
-  std::string err;
-  std::map<std::string, Tensor> w;
-  bool finalized = false;
-  int gemm_engine = STTRAN_GEMM_FP32_MFMA;
-  bool planes_ready = false;
-  // derived parameters
-  DevBuf derived;               // one arena for all derived tensors
-  float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
-  float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
-  void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
-  float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
-  std::vector<DecLayer> dec;
-  // workspace
+// Everything ONE forward in flight needs for itself: workspace, stream-K park space, index-map / chunk-table staging and
+// their caches, the device-side error flag.  A handle owns one lane (the classic `sttran_forward` on the caller's stream)
+// or several (`sttran_set_lanes` + `sttran_forward_lane`: each lane runs on its OWN stream, forked from the caller's with
+// an event, so consecutive one-clip calls -- the reference's loop, tools/test_STTran.py:81-84 -- overlap on the device).
+// The weights and derived parameters are shared (read-only during forwards).
+struct Lane {
   int64_t capP = 0, capB = 0;
   DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
   DevBuf dsg;                   // DSG-DETR: class-sequence tables built on the device (launch_dsg_layout)
@@ -142,6 +134,32 @@ struct SttranHandle {
     int num_clips = 0;
     bool dsg_device = false;      // the class sequences of this layout are built on the device
   } lay;
+  int32_t* im_host = nullptr;   // pinned scratch for the im_idx read-back
+  size_t im_host_cap = 0;
+  // ordering: `own` = the lane's stream (sttran_forward_lane), fork_ev = recorded on the caller's stream when a lane call
+  // starts, done_ev = recorded behind the last kernel of every forward on the stream it ran on (`last`): a later forward
+  // of this lane on ANOTHER stream first waits for it (the cached uploads and the workspace belong to the earlier one)
+  hipStream_t own = nullptr, last = nullptr;
+  hipEvent_t fork_ev = nullptr, done_ev = nullptr;
+  bool used = false;
+};
+
+struct SttranHandle {
+  SttranConfig cfg{};
+  std::string err;
+  std::map<std::string, Tensor> w;
+  bool finalized = false;
+  int gemm_engine = STTRAN_GEMM_FP32_MFMA;
+  bool planes_ready = false;
+  // derived parameters
+  DevBuf derived;               // one arena for all derived tensors
+  float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
+  float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
+  void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
+  float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
+  std::vector<DecLayer> dec;
+  std::vector<Lane*> lanes;     // >= 1
+  Lane* L = nullptr;            // the lane of the call in progress (calls on a handle are serialised by the caller)
   // profiling
   bool prof_on = false;
   std::vector<ProfEvent> prof_ev;
@@ -149,8 +167,6 @@ struct SttranHandle {
   std::vector<SttranProfEntry> prof_entries;
   SttranProfile prof{};
   hipStream_t prof_stream = nullptr;
-  int32_t* im_host = nullptr;   // pinned scratch for the im_idx read-back
-  size_t im_host_cap = 0;
 };
 
 namespace {
@@ -303,9 +319,9 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
                int force_tile = 0, int force_split = 0) {
   if (M <= 0) return STTRAN_OK;
   GemmPlan plan = plan_gemm(M, N, K, force_tile, force_split);
-  if (gemm_slab_bytes() > h->slab.bytes) {
+  if (gemm_slab_bytes() > h->L->slab.bytes) {
     HIPCK(hipStreamSynchronize(s));
-    HIPCK(h->slab.ensure(gemm_slab_bytes()));
+    HIPCK(h->L->slab.ensure(gemm_slab_bytes()));
   }
   if (h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && (M >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL) &&
       N >= 128 && !force_tile) {
@@ -320,7 +336,7 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
       ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
                    "gemm_x3_kernel<X3Tile<256,128,4,2>,EpiLinear>", M, N, K);
       HIPCK(gemm_linear_x3(s, A, reinterpret_cast<const uint16_t*>(t.planes) + r0 * t.ld, t.ld, rows * t.ld, M, N, K, epi,
-                           h->slab.as<float>()));
+                           h->L->slab.as<float>()));
       return STTRAN_OK;
     }
   }
@@ -329,7 +345,7 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
                t16 ? std::string("gemm16_kernel<Tile16<") + tile_name(plan.tile) + ">,EpiLinear>"
                    : std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
-  HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->slab.as<float>(), 1));
+  HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->L->slab.as<float>(), 1));
   return STTRAN_OK;
 }
 
@@ -348,8 +364,8 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
   const SttranConfig& c = h->cfg;
   const int D = c.embed_dim, F = c.ffn_dim;
   const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (xin / xout included)
-  float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
-  float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>();
+  float* QKV = h->L->qkv.as<float>(); float* ATT = h->L->att.as<float>(); float* Y = h->L->ybuf.as<float>();
+  float* H = h->L->hbuf.as<float>(); float* F1 = h->L->f1.as<float>();
   int rc;
   if ((rc = run_linear(h, s, GemmOperand{xin, LD, nullptr}, W(h, p + ".self_attn.in_proj_weight"), M, 3 * D, D,
                        epi_plain(QKV, 3 * D, W(h, p + ".self_attn.in_proj_bias"))))) return rc;
@@ -378,52 +394,52 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
 }
 
 int ensure_workspace(SttranHandle* h, int64_t P, int64_t B) {
-  if (P <= h->capP && B <= h->capB) return STTRAN_OK;
+  if (P <= h->L->capP && B <= h->L->capB) return STTRAN_OK;
   HIPCK(hipDeviceSynchronize());
-  const int64_t cp = std::max(P, h->capP), cb = std::max(B, h->capB);
+  const int64_t cp = std::max(P, h->L->capP), cb = std::max(B, h->L->capB);
   // Every [rows, D] activation buffer has a row stride of LD = pad32(D) floats (1952 for D = 1936): rows start on
   // 128-byte lines, and the 16 pad columns -- zeroed here, never written by any kernel -- are what the GEMM A loader
   // reads for the K tail (B_KMAJOR_PAD), so nothing a previous call left behind can reach a later call's result.
   const int64_t D = h->cfg.embed_dim, LD = pad32(D), F = h->cfg.ffn_dim, tok = 2 * cp;
-  HIPCK(h->slab.ensure(gemm_slab_bytes()));
-  HIPCK(h->x0.ensure((size_t)cp * LD * 4));
-  HIPCK(h->ebuf.ensure((size_t)cp * LD * 4));
-  HIPCK(h->qkv.ensure((size_t)tok * 3 * D * 4));
-  HIPCK(h->att.ensure((size_t)tok * LD * 4));
-  HIPCK(h->ybuf.ensure((size_t)tok * LD * 4));
-  HIPCK(h->hbuf.ensure((size_t)tok * LD * 4));
-  HIPCK(h->f1.ensure((size_t)tok * pad32(F) * 4));
-  HIPCK(h->gbuf.ensure((size_t)tok * LD * 4));
-  HIPCK(h->uni.ensure((size_t)(cp + tok) * LD * 4));
-  HIPCK(h->vbuf.ensure((size_t)cp * 256 * 49 * 4));
-  HIPCK(h->c2.ensure((size_t)cp * 128 * 49 * 4));
-  HIPCK(h->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + 4096));
-  HIPCK(h->poff.ensure((size_t)cp * 4 * 8));
+  HIPCK(h->L->slab.ensure(gemm_slab_bytes()));
+  HIPCK(h->L->x0.ensure((size_t)cp * LD * 4));
+  HIPCK(h->L->ebuf.ensure((size_t)cp * LD * 4));
+  HIPCK(h->L->qkv.ensure((size_t)tok * 3 * D * 4));
+  HIPCK(h->L->att.ensure((size_t)tok * LD * 4));
+  HIPCK(h->L->ybuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->L->hbuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->L->f1.ensure((size_t)tok * pad32(F) * 4));
+  HIPCK(h->L->gbuf.ensure((size_t)tok * LD * 4));
+  HIPCK(h->L->uni.ensure((size_t)(cp + tok) * LD * 4));
+  HIPCK(h->L->vbuf.ensure((size_t)cp * 256 * 49 * 4));
+  HIPCK(h->L->c2.ensure((size_t)cp * 128 * 49 * 4));
+  HIPCK(h->L->idx.ensure((size_t)(kIdxIntsPerPair * cp + 64) * 4 + 4096));
+  HIPCK(h->L->poff.ensure((size_t)cp * 4 * 8));
   if (h->cfg.mode != STTRAN_MODE_PREDCLS) {
-    HIPCK(h->zbuf.ensure((size_t)cb * pad32(h->cfg.feat_dim + 328) * 4));
-    HIPCK(h->hobj.ensure((size_t)cb * 1024 * 4));
+    HIPCK(h->L->zbuf.ensure((size_t)cb * pad32(h->cfg.feat_dim + 328) * 4));
+    HIPCK(h->L->hobj.ensure((size_t)cb * 1024 * 4));
   }
-  h->capP = cp;
-  h->capB = cb;
-  h->cached_P = -1;     // the index buffer may have been re-allocated (and zeroed): the cached layout is gone
+  h->L->capP = cp;
+  h->L->capB = cb;
+  h->L->cached_P = -1;     // the index buffer may have been re-allocated (and zeroed): the cached layout is gone
   return STTRAN_OK;
 }
 
 // Small host tables (index maps, the chunk table) go to the device through a ring of pinned staging buffers: the
 // copy is enqueue-only, and a slot is reused only after the copy that read it has completed.
 int upload_staged(SttranHandle* h, hipStream_t s, const void* src, size_t bytes, void* dst) {
-  const int k = h->stage_next;
-  h->stage_next = (k + 1) % SttranHandle::kStages;
-  if (h->stage_ev[k]) HIPCK(hipEventSynchronize(h->stage_ev[k]));
-  else HIPCK(hipEventCreateWithFlags(&h->stage_ev[k], hipEventDisableTiming));
-  if (h->stage_cap[k] < bytes) {
-    if (h->stage[k]) HIPCK(hipHostFree(h->stage[k]));
-    HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->stage[k]), bytes + 4096));
-    h->stage_cap[k] = bytes + 4096;
+  const int k = h->L->stage_next;
+  h->L->stage_next = (k + 1) % Lane::kStages;
+  if (h->L->stage_ev[k]) HIPCK(hipEventSynchronize(h->L->stage_ev[k]));
+  else HIPCK(hipEventCreateWithFlags(&h->L->stage_ev[k], hipEventDisableTiming));
+  if (h->L->stage_cap[k] < bytes) {
+    if (h->L->stage[k]) HIPCK(hipHostFree(h->L->stage[k]));
+    HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->L->stage[k]), bytes + 4096));
+    h->L->stage_cap[k] = bytes + 4096;
   }
-  memcpy(h->stage[k], src, bytes);
-  HIPCK(hipMemcpyAsync(dst, h->stage[k], bytes, hipMemcpyHostToDevice, s));
-  HIPCK(hipEventRecord(h->stage_ev[k], s));
+  memcpy(h->L->stage[k], src, bytes);
+  HIPCK(hipMemcpyAsync(dst, h->L->stage[k], bytes, hipMemcpyHostToDevice, s));
+  HIPCK(hipEventRecord(h->L->stage_ev[k], s));
   return STTRAN_OK;
 }
 
@@ -435,13 +451,13 @@ int upload_staged(SttranHandle* h, hipStream_t s, const void* src, size_t bytes,
 //                   (lib/transformer.py:179-185); clips with one frame keep the encoder row
 //                   (lib/transformer_wk.py:187-188)
 void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P,
-                  std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+                  std::vector<int32_t>& buf, Lane::Layout& L) {
   const int T = (int)counts.size();
   std::vector<int64_t> off(T + 1, 0);
   for (int t = 0; t < T; ++t) off[t + 1] = off[t] + counts[t];
   std::vector<int32_t> enc_off, enc_len, dec_off, dec_len, dec_src, out_src(P), need, qbegin, tok0(P, -1), tok1(P, -1);
   std::vector<uint8_t> slot;
-  L = SttranHandle::Layout();
+  L = Lane::Layout();
   for (int t = 0; t < T; ++t)
     if (counts[t] > 0) { enc_off.push_back((int32_t)off[t]); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
   for (int64_t p = 0; p < P; ++p) out_src[p] = (int32_t)p;
@@ -500,10 +516,10 @@ void build_layout(const std::vector<int32_t>& counts, const std::vector<int32_t>
 // Stored in the STTran slots: dec_off/dec_len = class sequences, dec_src = pair of each token,
 // need = PE row of each token, out_src = P + token of each pair.
 void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P,
-                      const int64_t* pair_idx, const int64_t* labels, std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+                      const int64_t* pair_idx, const int64_t* labels, std::vector<int32_t>& buf, Lane::Layout& L) {
   const int T = (int)counts.size();
   std::vector<int32_t> enc_off, enc_len, cls_off, cls_len, tok_pair, tok_pos, out_src(P);
-  L = SttranHandle::Layout();
+  L = Lane::Layout();
   int64_t o = 0;
   for (int t = 0; t < T; ++t) {
     if (counts[t] > 0) { enc_off.push_back((int32_t)o); enc_len.push_back(counts[t]); L.max_enc = std::max(L.max_enc, counts[t]); }
@@ -553,9 +569,9 @@ void build_layout_dsg(const std::vector<int32_t>& counts, const std::vector<int3
 // pair range of every clip; the class sequences are built by launch_dsg_layout from labels / pair_idx where they live.
 // n_dec_seq = one slot per (clip, class), max_dec = the largest clip (an upper bound of every class sequence).
 void build_layout_dsg_static(const std::vector<int32_t>& counts, const std::vector<int32_t>& clips, int64_t P, int NC,
-                             std::vector<int32_t>& buf, SttranHandle::Layout& L) {
+                             std::vector<int32_t>& buf, Lane::Layout& L) {
   std::vector<int32_t> enc_off, enc_len, clip_start;
-  L = SttranHandle::Layout();
+  L = Lane::Layout();
   int64_t o = 0;
   size_t t = 0;
   for (size_t c = 0; c < clips.size(); ++c) {
@@ -580,6 +596,41 @@ void build_layout_dsg_static(const std::vector<int32_t>& counts, const std::vect
   L.o_clip_start = put(clip_start);
   L.total_ints = buf.size();
 }
+
+// ---- lanes ---------------------------------------------------------------------------------------
+int lane_create(SttranHandle* h, Lane** out) {
+  Lane* L = new Lane();
+  if (hipMalloc(reinterpret_cast<void**>(&L->err_flag), 64) != hipSuccess || hipMemset(L->err_flag, 0, 64) != hipSuccess ||
+      hipStreamCreateWithFlags(&L->own, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&L->done_ev, hipEventDisableTiming) != hipSuccess) {
+    delete L;
+    return fail(h, STTRAN_ERR_HIP, "lane: stream / event / flag allocation failed");
+  }
+  *out = L;
+  return STTRAN_OK;
+}
+void lane_destroy(Lane* L) {
+  if (!L) return;
+  for (DevBuf* b : {&L->x0, &L->qkv, &L->att, &L->ybuf, &L->hbuf, &L->f1, &L->gbuf, &L->uni, &L->vbuf, &L->c2, &L->slab, &L->idx,
+                    &L->zbuf, &L->hobj, &L->ebuf, &L->dsg, &L->ctab, &L->poff})
+    b->release();
+  for (int i = 0; i < Lane::kStages; ++i) {
+    if (L->stage[i]) hipHostFree(L->stage[i]);
+    if (L->stage_ev[i]) hipEventDestroy(L->stage_ev[i]);
+  }
+  if (L->im_host) hipHostFree(L->im_host);
+  if (L->err_flag) hipFree(L->err_flag);
+  if (L->fork_ev) hipEventDestroy(L->fork_ev);
+  if (L->done_ev) hipEventDestroy(L->done_ev);
+  if (L->own) hipStreamDestroy(L->own);
+  delete L;
+}
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, hipStream_t s);
 
 }  // namespace
 
@@ -607,10 +658,13 @@ int sttran_create(const SttranConfig* cfg, SttranHandle** out) {
   SttranHandle* h = new SttranHandle();
   h->cfg = *cfg;
   declare_weights(h);
-  if (hipMalloc(&h->err_flag, 64) != hipSuccess || hipMemset(h->err_flag, 0, 64) != hipSuccess) {
+  Lane* l0 = nullptr;
+  if (lane_create(h, &l0) != STTRAN_OK) {
     delete h;
     return STTRAN_ERR_HIP;
   }
+  h->lanes.push_back(l0);
+  h->L = l0;
   *out = h;
   return STTRAN_OK;
 }
@@ -624,16 +678,9 @@ void sttran_destroy(SttranHandle* h) {
     if (kv.second.planes) hipFree(kv.second.planes);
   }
   if (h->w4_planes) hipFree(h->w4_planes);
-  for (DevBuf* b : {&h->derived, &h->x0, &h->qkv, &h->att, &h->ybuf, &h->hbuf, &h->f1, &h->gbuf, &h->uni, &h->vbuf,
-                    &h->c2, &h->slab, &h->idx, &h->zbuf, &h->hobj, &h->ebuf, &h->dsg, &h->ctab, &h->poff})
-    b->release();
-  for (int i = 0; i < SttranHandle::kStages; ++i) {
-    if (h->stage[i]) hipHostFree(h->stage[i]);
-    if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
-  }
-  if (h->im_host) hipHostFree(h->im_host);
+  h->derived.release();
+  for (Lane* L : h->lanes) lane_destroy(L);
   for (auto& e : h->prof_ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  if (h->err_flag) hipFree(h->err_flag);
   delete h;
 }
 
@@ -789,7 +836,49 @@ int sttran_set_gemm_engine(SttranHandle* h, int32_t engine) {
 int sttran_reserve(SttranHandle* h, int64_t max_pairs, int64_t max_boxes) {
   if (!h || max_pairs < 0 || max_boxes < 0) return STTRAN_ERR_INVALID;
   HIPCK(hipSetDevice(h->cfg.device));
-  return ensure_workspace(h, max_pairs, max_boxes);
+  int rc = STTRAN_OK;
+  Lane* keep = h->L;
+  for (Lane* L : h->lanes) {
+    h->L = L;
+    if ((rc = ensure_workspace(h, max_pairs, max_boxes))) break;
+  }
+  h->L = keep;
+  return rc;
+}
+
+int sttran_set_lanes(SttranHandle* h, int32_t lanes) {
+  if (!h || lanes < 1 || lanes > STTRAN_MAX_LANES) return fail(h, STTRAN_ERR_INVALID, "set_lanes: 1 .. STTRAN_MAX_LANES");
+  HIPCK(hipSetDevice(h->cfg.device));
+  HIPCK(hipDeviceSynchronize());                         // nothing of this handle is in flight while lanes come and go
+  while ((int)h->lanes.size() > lanes) { lane_destroy(h->lanes.back()); h->lanes.pop_back(); }
+  while ((int)h->lanes.size() < lanes) {
+    Lane* L = nullptr;
+    int rc = lane_create(h, &L);
+    if (rc) return rc;
+    h->lanes.push_back(L);
+  }
+  h->L = h->lanes[0];
+  return STTRAN_OK;
+}
+
+int32_t sttran_num_lanes(SttranHandle* h) { return h ? (int32_t)h->lanes.size() : 0; }
+
+int sttran_lane_stream(SttranHandle* h, int32_t lane, void** stream) {
+  if (!h || !stream || lane < 0 || lane >= (int)h->lanes.size()) return STTRAN_ERR_INVALID;
+  *stream = h->lanes[lane]->own;
+  return STTRAN_OK;
+}
+
+int sttran_lane_join(SttranHandle* h, int32_t lane, void* stream_) {
+  if (!h || lane < -1 || lane >= (int)h->lanes.size()) return STTRAN_ERR_INVALID;
+  HIPCK(hipSetDevice(h->cfg.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+  for (int i = 0; i < (int)h->lanes.size(); ++i) {
+    Lane* L = h->lanes[i];
+    if ((lane >= 0 && i != lane) || !L->used || L->last == s) continue;
+    HIPCK(hipStreamWaitEvent(s, L->done_ev, 0));
+  }
+  return STTRAN_OK;
 }
 
 int sttran_profile_enable(SttranHandle* h, int32_t enable) {
@@ -811,6 +900,8 @@ int sttran_profile_reset(SttranHandle* h) {
 int sttran_profile_read(SttranHandle* h, SttranProfile* out) {
   if (!h || !out || out->struct_size != sizeof(SttranProfile)) return STTRAN_ERR_INVALID;
   HIPCK(hipStreamSynchronize(h->prof_stream));
+  for (Lane* L : h->lanes)
+    if (L->used) HIPCK(hipEventSynchronize(L->done_ev));
   for (auto& e : h->prof_ev) {
     float ms = 0.f;
     HIPCK(hipEventElapsedTime(&ms, e.a, e.b));
@@ -832,8 +923,45 @@ int sttran_profile_entries(SttranHandle* h, SttranProfEntry* out, int32_t cap, i
   return STTRAN_OK;
 }
 
-int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, void* stream_) {
+// run one forward of lane L on stream x, ordered behind the lane's previous forward if that ran on another stream
+static int forward_ordered(SttranHandle* h, Lane* L, const SttranInputs* in, const SttranOutputs* out, hipStream_t x) {
+  const bool cap = capturing(x);                   // a capture records kernels only; replays are ordered by their owner
+  if (!cap && L->used && L->last != x) HIPCK(hipStreamWaitEvent(x, L->done_ev, 0));
+  h->L = L;
+  const int rc = forward_on(h, in, out, x);
+  h->L = h->lanes[0];
+  if (!cap) {
+    // (also after a failed call: whatever it enqueued before failing still runs on x)
+    HIPCK(hipEventRecord(L->done_ev, x));
+    L->last = x; L->used = true;
+  }
+  return rc;
+}
+
+int sttran_forward(SttranHandle* h, const SttranInputs* in, const SttranOutputs* out, void* stream_) {
   if (!h) return STTRAN_ERR_INVALID;
+  if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(h, STTRAN_ERR_HIP, "hipSetDevice");
+  return forward_ordered(h, h->lanes[0], in, out, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int sttran_forward_lane(SttranHandle* h, int32_t lane, const SttranInputs* in, const SttranOutputs* out, void* stream_) {
+  if (!h) return STTRAN_ERR_INVALID;
+  if (lane < 0 || lane >= (int)h->lanes.size()) return fail(h, STTRAN_ERR_INVALID, "forward_lane: no such lane (sttran_set_lanes)");
+  HIPCK(hipSetDevice(h->cfg.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+  Lane* L = h->lanes[lane];
+  if (capturing(s)) return fail(h, STTRAN_ERR_INVALID, "forward_lane: the caller's stream is being captured (use sttran_forward)");
+  // fork: everything the caller enqueued on `s` so far (the producer of this entry's tensors) precedes the lane's work
+  HIPCK(hipEventRecord(L->fork_ev, s));
+  HIPCK(hipStreamWaitEvent(L->own, L->fork_ev, 0));
+  return forward_ordered(h, L, in, out, L->own);     // no join: sttran_lane_join / sttran_sync_check order a consumer
+}
+
+}  // extern "C"
+
+namespace {
+
+int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, hipStream_t s) {
   static_assert(offsetof(SttranInputs, clip_features) == STTRAN_INPUTS_V1_SIZE, "STTRAN_INPUTS_V1_SIZE");
   if (!in_ || !out || (in_->struct_size != sizeof(SttranInputs) && in_->struct_size != STTRAN_INPUTS_V1_SIZE) ||
       out->struct_size != sizeof(SttranOutputs))
@@ -878,8 +1006,6 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
       return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs boxes and distribution");
   }
   if (oc && !out->distribution) return fail(h, STTRAN_ERR_INVALID, "forward: sgdet needs an output distribution");
-  HIPCK(hipSetDevice(c.device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
   h->prof_stream = s;
   int rc;
   if (!h->finalized && (rc = sttran_finalize_weights(h))) return rc;
@@ -905,6 +1031,7 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
       HIPCK(split_planes(s, h->w4_perm, 1152, 256, 1152, h->w4_planes, 1152));
     }
     h->planes_ready = true;
+    if (h->lanes.size() > 1) HIPCK(hipStreamSynchronize(s));      // the other lanes' streams read the planes too
   }
   if ((rc = ensure_workspace(h, P, B))) return rc;
 
@@ -915,19 +1042,19 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
   } else {
     if (!in->im_idx) return fail(h, STTRAN_ERR_INVALID, "forward: neither frame_counts nor im_idx given");
     const size_t esz = in->im_idx_dtype == STTRAN_DTYPE_I64 ? 8 : 4;
-    if (h->im_host_cap < (size_t)P * 8) {
-      if (h->im_host) HIPCK(hipHostFree(h->im_host));
-      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->im_host), (size_t)P * 8));
-      h->im_host_cap = (size_t)P * 8;
+    if (h->L->im_host_cap < (size_t)P * 8) {
+      if (h->L->im_host) HIPCK(hipHostFree(h->L->im_host));
+      HIPCK(hipHostMalloc(reinterpret_cast<void**>(&h->L->im_host), (size_t)P * 8));
+      h->L->im_host_cap = (size_t)P * 8;
     }
-    HIPCK(hipMemcpyAsync(h->im_host, in->im_idx, (size_t)P * esz, hipMemcpyDeviceToHost, s));
+    HIPCK(hipMemcpyAsync(h->L->im_host, in->im_idx, (size_t)P * esz, hipMemcpyDeviceToHost, s));
     HIPCK(hipStreamSynchronize(s));
     int64_t prev = -1;
     for (int64_t p = 0; p < P; ++p) {
       int64_t f;
-      if (in->im_idx_dtype == STTRAN_DTYPE_I64) f = reinterpret_cast<const int64_t*>(h->im_host)[p];
-      else if (in->im_idx_dtype == STTRAN_DTYPE_I32) f = h->im_host[p];
-      else f = (int64_t)reinterpret_cast<const float*>(h->im_host)[p];
+      if (in->im_idx_dtype == STTRAN_DTYPE_I64) f = reinterpret_cast<const int64_t*>(h->L->im_host)[p];
+      else if (in->im_idx_dtype == STTRAN_DTYPE_I32) f = h->L->im_host[p];
+      else f = (int64_t)reinterpret_cast<const float*>(h->L->im_host)[p];
       if (f < prev || f < 0) return fail(h, STTRAN_ERR_ORDER, "forward: im_idx must be non-negative and sorted ascending");
       if ((size_t)f >= counts.size()) counts.resize((size_t)f + 1, 0);
       counts[(size_t)f]++;
@@ -963,11 +1090,11 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
   static const bool dsg_host_env = getenv("STTRAN_DSG_HOST_LAYOUT") && atoi(getenv("STTRAN_DSG_HOST_LAYOUT")) != 0;
   const bool dsg_dev = is_dsg && !dsg_host_env;
   const bool host_dsg = is_dsg && !dsg_dev;
-  if (host_dsg || !(P == h->cached_P && counts == h->cached_counts && clips == h->cached_clips && h->lay.dsg_device == dsg_dev)) {
+  if (host_dsg || !(P == h->L->cached_P && counts == h->L->cached_counts && clips == h->L->cached_clips && h->L->lay.dsg_device == dsg_dev)) {
     std::vector<int32_t> buf;
-    h->cached_P = -1;      // h->lay is about to change: the cache only becomes valid again once the upload is enqueued
+    h->L->cached_P = -1;      // h->L->lay is about to change: the cache only becomes valid again once the upload is enqueued
     if (dsg_dev) {
-      build_layout_dsg_static(counts, clips, P, c.num_obj_classes, buf, h->lay);
+      build_layout_dsg_static(counts, clips, P, c.num_obj_classes, buf, h->L->lay);
     } else if (is_dsg) {
       if (tables) return fail(h, STTRAN_ERR_INVALID, "forward: STTRAN_DSG_HOST_LAYOUT=1 reads a contiguous pair_idx (no pointer tables)");
       // the class sequences depend on labels[pair_idx[:,1]]: read both back (small) -- DSG-DETR is the
@@ -978,19 +1105,19 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
       HIPCK(hipStreamSynchronize(s));
       for (int64_t p = 0; p < 2 * P; ++p)
         if (hp[p] < 0 || hp[p] >= B) return fail(h, STTRAN_ERR_INVALID, "forward: pair_idx out of range");
-      build_layout_dsg(counts, clips, P, hp.data(), hl.data(), buf, h->lay);
+      build_layout_dsg(counts, clips, P, hp.data(), hl.data(), buf, h->L->lay);
       for (size_t i = 0; i < (size_t)P; ++i)
-        if (buf[h->lay.o_need + i] >= 400) return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence");
+        if (buf[h->L->lay.o_need + i] >= 400) return fail(h, STTRAN_ERR_LIMIT, "forward: more than 400 frames in a class sequence");
     } else {
-      build_layout(counts, clips, P, buf, h->lay);
+      build_layout(counts, clips, P, buf, h->L->lay);
     }
     // (no limit on the pairs of a frame / window / class sequence: the attention streams its keys in chunks)
-    if ((int64_t)buf.size() > kIdxIntsPerPair * h->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
-    if ((rc = upload_staged(h, s, buf.data(), buf.size() * 4, h->idx.p))) return rc;
-    h->cached_P = host_dsg ? -1 : P; h->cached_counts = counts; h->cached_clips = clips;
+    if ((int64_t)buf.size() > kIdxIntsPerPair * h->L->capP + 64) return fail(h, STTRAN_ERR_INVALID, "forward: index buffer too small");
+    if ((rc = upload_staged(h, s, buf.data(), buf.size() * 4, h->L->idx.p))) return rc;
+    h->L->cached_P = host_dsg ? -1 : P; h->L->cached_counts = counts; h->L->cached_clips = clips;
   }
-  const SttranHandle::Layout& L = h->lay;
-  const int32_t* ib = h->idx.as<int32_t>();
+  const Lane::Layout& L = h->L->lay;
+  const int32_t* ib = h->L->idx.as<int32_t>();
   const int* enc_off = ib + L.o_enc_off; const int* enc_len = ib + L.o_enc_len;
   const int* dec_off = ib + L.o_dec_off; const int* dec_len = ib + L.o_dec_len;
   const int* dec_src = ib + L.o_dec_src; const int* out_src = ib + L.o_out_src;
@@ -1003,8 +1130,8 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     // dec_src, need, out_src per token / pair, then 4 P ints of scratch (launched behind pair_prep, which resolves the
     // pairs' classes and subjects through the chunk table)
     const int64_t Kseq = L.n_dec_seq;
-    HIPCK(h->dsg.ensure((size_t)(2 * Kseq + 7 * P + 64) * 4));
-    int* d = h->dsg.as<int32_t>();
+    HIPCK(h->L->dsg.ensure((size_t)(2 * Kseq + 7 * P + 64) * 4));
+    int* d = h->L->dsg.as<int32_t>();
     dec_off = d; dec_len = d + Kseq; dec_src = d + 2 * Kseq; need = d + 2 * Kseq + P; out_src = d + 2 * Kseq + 2 * P;
     dsg_scratch = d + 2 * Kseq + 3 * P;
   }
@@ -1036,33 +1163,33 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     feat_base = reinterpret_cast<const float*>(ptr[0 * (size_t)n + base]);
     union_base = reinterpret_cast<const float*>(ptr[3 * (size_t)n + base]);
     mask_base = reinterpret_cast<const float*>(ptr[4 * (size_t)n + base]);
-    if (t != h->ctab_host) {
-      h->ctab_host.clear();
-      if (h->ctab.bytes < t.size() * 8) { HIPCK(hipStreamSynchronize(s)); HIPCK(h->ctab.ensure(t.size() * 8 * 2)); }
-      if ((rc = upload_staged(h, s, t.data(), t.size() * 8, h->ctab.p))) return rc;
-      h->ctab_host = t;
+    if (t != h->L->ctab_host) {
+      h->L->ctab_host.clear();
+      if (h->L->ctab.bytes < t.size() * 8) { HIPCK(hipStreamSynchronize(s)); HIPCK(h->L->ctab.ensure(t.size() * 8 * 2)); }
+      if ((rc = upload_staged(h, s, t.data(), t.size() * 8, h->L->ctab.p))) return rc;
+      h->L->ctab_host = t;
     }
-    const int64_t* d = h->ctab.as<int64_t>();
+    const int64_t* d = h->L->ctab.as<int64_t>();
     auto arr = [&](int k) { return reinterpret_cast<const void* const*>(d + 2 * (n + 1) + (size_t)k * n); };
     tab.n = n; tab.base = base; tab.pair_start = d; tab.box_start = d + n + 1;
     tab.features = arr(0); tab.pair_idx = arr(1); tab.labels = arr(2); tab.union_feat = arr(3); tab.masks = arr(4);
     tab.boxes = arr(5); tab.dist = arr(6);
   }
-  int64_t* feat_off = h->poff.as<int64_t>();          // [2][P] subject / object feature rows
+  int64_t* feat_off = h->L->poff.as<int64_t>();          // [2][P] subject / object feature rows
   int64_t* union_off = feat_off + 2 * P;              // [P]
   int64_t* mask_off = feat_off + 3 * P;               // [P]
 
   const int D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
   const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (ensure_workspace)
-  float* X0 = h->x0.as<float>();
-  float* QKV = h->qkv.as<float>(); float* ATT = h->att.as<float>(); float* Y = h->ybuf.as<float>();
-  float* H = h->hbuf.as<float>(); float* F1 = h->f1.as<float>(); float* G = h->gbuf.as<float>();
-  float* UNI = h->uni.as<float>(); float* V = h->vbuf.as<float>(); float* C2 = h->c2.as<float>();
-  float* E = h->ebuf.as<float>();
+  float* X0 = h->L->x0.as<float>();
+  float* QKV = h->L->qkv.as<float>(); float* ATT = h->L->att.as<float>(); float* Y = h->L->ybuf.as<float>();
+  float* H = h->L->hbuf.as<float>(); float* F1 = h->L->f1.as<float>(); float* G = h->L->gbuf.as<float>();
+  float* UNI = h->L->uni.as<float>(); float* V = h->L->vbuf.as<float>(); float* C2 = h->L->c2.as<float>();
+  float* E = h->L->ebuf.as<float>();
 
   // ---- ObjectClassifier, sgdet + is_wks (lib/sttran.py:173-184) ------------------------------
   if (oc) {
-    float* Z = h->zbuf.as<float>(); float* HO = h->hobj.as<float>();
+    float* Z = h->L->zbuf.as<float>(); float* HO = h->L->hobj.as<float>();
     const int zd = FD + 200 + 128;
     const int64_t ldz = pad32(zd);
     {
@@ -1083,14 +1210,14 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     ProfScope ps(h, s, STTRAN_PROF_INDEX, 0, 4.0 * P * 400 * 2, "pair_prep_kernel", P, 400, 0);
     HIPCK(launch_pair_prep(s, tab, (int)P, FD, NC, W(h, "obj_embed.weight"), W(h, "obj_embed2.weight"), 200, feat_off,
                            union_off, mask_off, dsg_scratch, dsg_scratch ? dsg_scratch + P : nullptr, X0, (int)LD, 1536,
-                           h->err_flag));
+                           h->L->err_flag));
   }
   if (L.dsg_device) {
     const int64_t Kseq = L.n_dec_seq;
-    int* d = h->dsg.as<int32_t>();
+    int* d = h->L->dsg.as<int32_t>();
     HIPCK(launch_dsg_layout(s, nullptr, nullptr, (int)B, ib + L.o_clip_start, L.num_clips, c.num_obj_classes, (int)P, 400,
                             1 << 30, d, d + Kseq, d + 2 * Kseq, d + 2 * Kseq + P, d + 2 * Kseq + 2 * P, dsg_scratch,
-                            h->err_flag, L.max_dec));
+                            h->L->err_flag, L.max_dec));
   }
   // subject / object rows of `features` gathered by element offset (one chunk per clip: GemmOperand::rowoff)
   if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off}, W(h, "subj_fc.weight"), (int)P, 512, FD,
@@ -1118,11 +1245,11 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                                : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
     if (x3)
       HIPCK(launch_mask_conv2_x3(s, h->w4_planes, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
-                                 h->slab.as<float>()));
+                                 h->L->slab.as<float>()));
     else if (conv_t16)
-      HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->slab.as<float>()));
+      HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->L->slab.as<float>()));
     else
-      HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->slab.as<float>()));
+      HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->L->slab.as<float>()));
   }
   {
     const Tensor& wu = h->w["union_func1.weight"];
@@ -1134,13 +1261,13 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
                                : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
     if (x3)
       HIPCK(launch_union_conv_x3(s, union_base, union_off, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD,
-                                 h->slab.as<float>()));
+                                 h->L->slab.as<float>()));
     else if (conv_t16)
       HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
-                                  h->slab.as<float>()));
+                                  h->L->slab.as<float>()));
     else
       HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
-                              h->slab.as<float>()));
+                              h->L->slab.as<float>()));
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
                        epi_plain(X0 + 1024, LD, W(h, "vr_fc.bias"))))) return rc;
@@ -1259,20 +1386,30 @@ int sttran_forward(SttranHandle* h, const SttranInputs* in_, const SttranOutputs
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(P, nh, D), gemm_bytes(P, nh, D),
                  "gemm_sk_kernel<GemmTile<64,64,2,2,B_KMAJOR_PAD>,EpiHeads>", P, nh, D);
     HIPCK(gemm_heads(s, GemmOperand{UNI, LD, out_src}, GemmOperand{h->heads_w, pad32(D), nullptr}, (int)P, nh, D, eh, plan,
-                     h->slab.as<float>()));
+                     h->L->slab.as<float>()));
   }
   if (h->prof_on) h->prof.forwards += 1;
   return STTRAN_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int sttran_sync_check(SttranHandle* h, void* stream) {
   if (!h) return STTRAN_ERR_INVALID;
   HIPCK(hipSetDevice(h->cfg.device));
+  int rc = sttran_lane_join(h, -1, stream);            // every lane's last forward precedes the wait below
+  if (rc) return rc;
   HIPCK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
   int flag = 0;
-  HIPCK(hipMemcpy(&flag, h->err_flag, 4, hipMemcpyDeviceToHost));
+  for (Lane* L : h->lanes) {
+    int f = 0;
+    HIPCK(hipMemcpy(&f, L->err_flag, 4, hipMemcpyDeviceToHost));
+    if (f) HIPCK(hipMemset(L->err_flag, 0, 4));
+    flag |= f;
+  }
   if (flag) {
-    HIPCK(hipMemset(h->err_flag, 0, 4));
     if (flag & 1) return fail(h, STTRAN_ERR_INDEX, "forward: pair_idx or labels out of range (values were clamped)");
     return fail(h, STTRAN_ERR_LIMIT, "forward: a class sequence spans more than 400 frames (the reference's positional-encoding table, lib/dsg_detr.py:25-48, has 400 rows)");
   }

@@ -100,6 +100,13 @@ class STTran:
         # "bf16x3_all" = the emulation for every contraction whatever its row count (parity tests on small fixtures)
         self.gemm_engine = "fp32"
         self._engine_set = None
+        # lanes (include/sttran_hip.h "LANES"): `model.lanes = K` gives the handle K independent workspaces + streams;
+        # `forward_async(entry)` then runs call i on lane i % K without making the current stream wait, so the one-clip
+        # calls of the reference's loop overlap on the device; `join(entry)` orders a consumer behind the result.
+        self._lanes = 1
+        self._lanes_set = 1
+        self._next_lane = 0
+        self._lane_streams = {}
         self._device = None
         self._handle = None
         self._sd = {}
@@ -194,6 +201,8 @@ class STTran:
             self._lib.sttran_destroy(self._handle)
             self._handle = None
             self._engine_set = None
+            self._lanes_set = 1
+            self._lane_streams = {}
 
     def __del__(self):
         # Never during interpreter shutdown: module teardown order is arbitrary and the HIP runtime underneath
@@ -229,8 +238,67 @@ class STTran:
                  "K": arr[i].K, "launches": int(arr[i].launches), "ms": arr[i].ms, "flops": arr[i].flops}
                 for i in range(n.value)]
 
+    @property
+    def lanes(self):
+        return self._lanes
+
+    @lanes.setter
+    def lanes(self, n):
+        n = int(n)
+        if not 1 <= n <= 8:
+            raise ValueError("lanes must be 1..8")
+        self._lanes = n
+
+    def _sync_lanes(self):
+        if self._lanes_set != self._lanes:
+            nat.check(self._lib, self._handle, self._lib.sttran_set_lanes(self._handle, self._lanes))
+            self._lanes_set = self._lanes
+            self._next_lane = 0
+            self._lane_streams = {}
+
+    def _lane_stream(self, lane):
+        st = self._lane_streams.get(lane)
+        if st is None:
+            p = C.c_void_p()
+            nat.check(self._lib, self._handle, self._lib.sttran_lane_stream(self._handle, lane, C.byref(p)))
+            st = self._lane_streams[lane] = torch.cuda.ExternalStream(p.value, device=torch.device("cuda", self._device))
+        return st
+
+    def forward_async(self, entry):
+        """`forward(entry)` on the next lane (round robin over `model.lanes`), WITHOUT making the current stream wait for
+        it: the call returns as soon as the work is enqueued on the lane's own stream (forked from the current stream, so
+        whatever produced `entry` there precedes it).  The output tensors are valid for a consumer on the current stream
+        only after `model.join(entry)` (or `sync_check()`, which joins every lane).  The loop of tools/test_STTran.py:81-92
+        in this form keeps `lanes` clips in flight:
+
+            pending = collections.deque()
+            for entry, gt in loader:
+                pending.append((model.forward_async(entry), gt))
+                if len(pending) == model.lanes:
+                    pred, g = pending.popleft(); evaluator.evaluate_scene_graph(g, model.join(pred))
+
+        `check_indices` is not applied per call here (it would synchronise); index errors raise at `sync_check()`.
+        Results are bit-identical to `forward`'s."""
+        self._async = True
+        try:
+            return self.forward(entry)
+        finally:
+            self._async = False
+
+    def join(self, entry=None):
+        """Make the current stream wait for the lane that computed `entry` (None: for every lane); returns `entry`."""
+        if self._handle is not None:
+            lane = -1 if entry is None else int(entry.get("_lane", -1))
+            dev = torch.device("cuda", self._device)
+            nat.check(self._lib, self._handle,
+                      self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        return entry
+
+    _async = False
+
     def reserve(self, max_pairs, max_boxes):
         self._ensure_handle()
+        self._sync_lanes()
         nat.check(self._lib, self._handle, self._lib.sttran_reserve(self._handle, int(max_pairs), int(max_boxes)))
 
     # ---- forward ---------------------------------------------------------------------------------
@@ -273,6 +341,7 @@ class STTran:
         that avoid the read-back of `im_idx`: `frame_counts` (pairs per frame) and, for a batch of
         clips packed by `pack_clips`, `clip_num_frames`."""
         self._ensure_handle()
+        self._sync_lanes()
         lib, h = self._lib, self._handle
         if self._engine_set != self.gemm_engine:
             nat.check(lib, h, lib.sttran_set_gemm_engine(h, {"fp32": 0, "bf16x3": 1, "bf16x3_all": 2}[self.gemm_engine]))
@@ -404,9 +473,25 @@ class STTran:
                 taps[k] = torch.empty((P, 1936), dtype=f32, device=dev)
                 setattr(out, k + "_tap", taps[k].data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
-        nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
+        if self._async:
+            lane = self._next_lane
+            self._next_lane = (lane + 1) % self._lanes
+            nat.check(lib, h, lib.sttran_forward_lane(h, lane, C.byref(inp), C.byref(out), C.c_void_p(stream)))
+            # the lane's stream reads the inputs and writes the outputs: torch's caching allocator must not hand their
+            # memory to a later allocation on the current stream before the lane is done with it
+            ls = self._lane_stream(lane)
+            for t in [att, spa, con, dist_out] + list(taps.values()):
+                if t is not None:
+                    t.record_stream(ls)
+            for item in keep:
+                for t in (item if isinstance(item, (list, tuple)) else (item,)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(ls)
+            entry["_lane"] = lane
+        else:
+            nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
         del keep                                             # (the launches read device memory that `entry` keeps alive)
-        if self.check_indices:
+        if self.check_indices and not self._async:
             self.sync_check()
         # ---- the keys the reference writes (lib/sttran.py:91,182-184,404-409) ----
         lazy = isinstance(entry, PackedClips) and entry.by_pointer    # `pred_labels` / `pred_scores` alias on first access

@@ -18,19 +18,25 @@ def native():
     return _native
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "sttran_hip.h")).read()
+def _declared(header="sttran_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(sttran_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(sttran_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_header_symbols_exported(native):
+    """every entry point of the drop-in boundary (sttran_hip.h) and of the lab header (sttran_hip_debug.h) is exported
+    and bound; the boundary carries no test hook and no experiment switch"""
     lib = native.load()
-    names = _declared()
-    assert len(names) >= 15
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/sttran_hip.h but not exported"
-    assert sorted(s[0] for s in native.SYMBOLS) == names
+    names, lab = _declared(), _declared("sttran_hip_debug.h")
+    assert len(names) >= 20 and len(lab) >= 10
+    for n in names + lab:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+    assert sorted(s[0] for s in native.SYMBOLS) == sorted(names + lab)
+    assert not [n for n in names if "debug" in n or "engine" in n], "lab symbols in the product header"
+    assert all(n.startswith("sttran_debug_") or n == "sttran_set_gemm_engine" for n in lab)
+    for n in ("sttran_set_lanes", "sttran_forward_lane", "sttran_lane_join", "sttran_lane_stream", "sttran_num_lanes"):
+        assert n in names
 
 
 def test_version_and_null_handle(native):
