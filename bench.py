@@ -69,7 +69,10 @@ BF16X3_PEAK_TFLOPS = 16 * FP32_MFMA_PEAK_TFLOPS / 6    # the bf16x3 emulation's 
 # 16x12 rate goes 15.8 k (1 clip) -> 28.3 k (8) -> 30.2 k (16) -> 31.3 k (32) -> 32.0 k (64) -> 32.5 k (128) frames/s as
 # tile quantisation and the stream-K fix-ups amortise; `batch_sweep` in the line re-measures 1 / 16 / default every run.
 SHAPES = {"16x12": (16, 12, 64), "64x36": (64, 36, 4)}
-ONE_CLIP_LANES = 4                                              # calls in flight in the one-clip-per-pass leg
+# calls in flight in the one-clip-per-pass leg.  3 lanes + the caller's stream = the 4 hardware queues a HIP process gets by
+# default (GPU_MAX_HW_QUEUES): measured 2 / 3 / 4 / 6 / 8 lanes = 18.8 / 20.9 / 18.8 / 18.5 / 20.3 k frames/s on a box whose
+# serial rate was 14.4 k (tools/experiments/lanes_probe.py --api) -- more lanes than queues share queues again
+ONE_CLIP_LANES = 3
 SWEEP_CPS = {"16x12": 16, "64x36": 1}                           # the smaller batch of `batch_sweep` (round 1-2 defaults)
 
 
@@ -616,8 +619,8 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
     if one_clip and cps > 1 and world == 1:
         # two clips alternate (clip 0 of each batch: other tensors, other per-frame counts): every call is a new entry, as
         # in the reference's loop.  (a) `serial`: `model(entry)` on the caller's stream, one clip at a time -- rounds 1-3's
-        # figure; (b) LANES: the same calls as `model.forward_async(entry)` with 4 lanes in the handle -- call i runs on lane
-        # i % 4's own stream, its result is joined (event wait, no host synchronisation) three calls later, as a pipelined
+        # figure; (b) LANES: the same calls as `model.forward_async(entry)` with ONE_CLIP_LANES lanes in the handle -- call i runs
+        # on lane i % lanes' own stream, its result is joined (event wait, no host synchronisation) lanes - 1 calls later, as a pipelined
         # consumer would: one call's launch ramps / prologues / epilogues run under the other calls' MFMAs.
         import collections
         ones = [b[0] for b in batches]

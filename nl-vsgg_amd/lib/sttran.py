@@ -106,7 +106,7 @@ class STTran:
         self._lanes = 1
         self._lanes_set = 1
         self._next_lane = 0
-        self._lane_streams = {}
+        self._inflight = {}             # lane -> tensors of its last un-joined call (see _run)
         self._device = None
         self._handle = None
         self._sd = {}
@@ -202,7 +202,7 @@ class STTran:
             self._handle = None
             self._engine_set = None
             self._lanes_set = 1
-            self._lane_streams = {}
+            self._inflight = {}
 
     def __del__(self):
         # Never during interpreter shutdown: module teardown order is arbitrary and the HIP runtime underneath
@@ -252,17 +252,9 @@ class STTran:
     def _sync_lanes(self):
         if self._lanes_set != self._lanes:
             nat.check(self._lib, self._handle, self._lib.sttran_set_lanes(self._handle, self._lanes))
-            self._lanes_set = self._lanes
+            self._lanes_set = self._lanes          # (sttran_set_lanes synchronised the device: nothing is in flight)
             self._next_lane = 0
-            self._lane_streams = {}
-
-    def _lane_stream(self, lane):
-        st = self._lane_streams.get(lane)
-        if st is None:
-            p = C.c_void_p()
-            nat.check(self._lib, self._handle, self._lib.sttran_lane_stream(self._handle, lane, C.byref(p)))
-            st = self._lane_streams[lane] = torch.cuda.ExternalStream(p.value, device=torch.device("cuda", self._device))
-        return st
+            self._inflight = {}
 
     def forward_async(self, entry):
         """`forward(entry)` on the next lane (round robin over `model.lanes`), WITHOUT making the current stream wait for
@@ -292,6 +284,10 @@ class STTran:
             dev = torch.device("cuda", self._device)
             nat.check(self._lib, self._handle,
                       self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            if lane < 0:
+                self._inflight = {}
+            else:
+                self._inflight.pop(lane, None)
         return entry
 
     _async = False
@@ -328,6 +324,7 @@ class STTran:
         last check (what `check_indices=True` does after every call)."""
         stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
         rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
+        self._inflight = {}                             # sync_check joined every lane and waited
         if rc == 7:                                     # STTRAN_ERR_INDEX: what torch raises as an IndexError
             msg = self._lib.sttran_last_error(self._handle) or b""
             raise nat.SttranIndexError(rc, msg.decode("utf-8", "replace"))
@@ -476,17 +473,15 @@ class STTran:
         if self._async:
             lane = self._next_lane
             self._next_lane = (lane + 1) % self._lanes
+            # The lane's stream reads the inputs and writes the outputs after this call has returned.  torch's caching
+            # allocator only knows the CURRENT stream: a tensor dropped by the caller would be handed to a later allocation
+            # there while the lane is still using it.  So the shim keeps a reference to every tensor of the call until the
+            # lane has been joined into the current stream (`join`, `sync_check`) -- or until the lane's next call, which
+            # joins it first (that call was issued `lanes` calls ago: the wait is normally already satisfied).
+            if self._inflight.get(lane):
+                nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(stream)))
             nat.check(lib, h, lib.sttran_forward_lane(h, lane, C.byref(inp), C.byref(out), C.c_void_p(stream)))
-            # the lane's stream reads the inputs and writes the outputs: torch's caching allocator must not hand their
-            # memory to a later allocation on the current stream before the lane is done with it
-            ls = self._lane_stream(lane)
-            for t in [att, spa, con, dist_out] + list(taps.values()):
-                if t is not None:
-                    t.record_stream(ls)
-            for item in keep:
-                for t in (item if isinstance(item, (list, tuple)) else (item,)):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(ls)
+            self._inflight[lane] = (keep, att, spa, con, dist_out, taps)
             entry["_lane"] = lane
         else:
             nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))

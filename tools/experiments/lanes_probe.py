@@ -24,12 +24,40 @@ def main():
     ap.add_argument("--lanes", default="1,2,3,4")
     ap.add_argument("--calls", type=int, default=200)
     ap.add_argument("--workload", default="16x12")
+    ap.add_argument("--api", action="store_true", help="ONE handle with `model.lanes = K` (forward_async / join) instead of K handles")
+    ap.add_argument("--join", default="lag", choices=["lag", "end"], help="--api: join call i - K + 1 after submitting call i, or only at the end")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     T, N, _ = bench.SHAPES[a.workload]
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_sttran_state_dict(7).items()}
     gen = torch.Generator(device=dev).manual_seed(1234)
     clips = [bench.device_clip(T, N, gen, dev, shifted=bool(i & 1)) for i in range(8)]
+    if a.api:
+        import collections
+        m = STTran(mode="predcls", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=bench.CLASSES,
+                   enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(dev)
+        m.eval(); m.check_indices = False
+        m.load_state_dict(sd, strict=False)
+        for lanes in [int(x) for x in a.lanes.split(",")]:
+            m.lanes = lanes
+
+            def run(n):
+                pending = collections.deque()
+                for i in range(n):
+                    pending.append(m.forward_async(dict(clips[i % len(clips)])))
+                    if a.join == "lag" and len(pending) == lanes:
+                        m.join(pending.popleft())
+                m.join()
+            run(4 * lanes)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(a.calls)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            print(f"api lanes {lanes} join={a.join}: {1e3 * (t2 - t0) / a.calls:.3f} ms/clip  {a.calls * T / (t2 - t0):.0f} frames/s   "
+                  f"(host enqueue {1e3 * (t1 - t0) / a.calls:.3f} ms/clip)", flush=True)
+        return
     for lanes in [int(x) for x in a.lanes.split(",")]:
         models, streams = [], []
         for l in range(lanes):
