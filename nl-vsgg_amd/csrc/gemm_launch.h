@@ -29,7 +29,7 @@ static SkPlan sk_plan(int tile, int64_t tiles, int64_t ksteps) {
 #endif
   SkPlan p;
   // never cut finer than kMinSteps K-steps per workgroup: below that the per-segment prologue dominates
-  static const int kMinSteps = getenv("STTRAN_SK_MIN_STEPS") ? std::max(1, atoi(getenv("STTRAN_SK_MIN_STEPS"))) : 4;
+  static const int kMinSteps = exp_env("STTRAN_SK_MIN_STEPS") ? std::max(1, atoi(exp_env("STTRAN_SK_MIN_STEPS"))) : 4;
   p.G = (int)std::min<int64_t>(g, std::max<int64_t>(1, tiles * ksteps / kMinSteps));
   p.dp_per_wg = (int)(tiles / p.G);
   p.tiles_sk = (int)(tiles - (int64_t)p.dp_per_wg * p.G);
@@ -61,7 +61,7 @@ static hipError_t launch_tile_p(hipStream_t s, int tile_id, const GemmOperand& A
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
   // more than one workgroup per CU: the second-dispatched ones walk their work in the opposite order (see the kernel)
-  static const int env_stagger = getenv("STTRAN_GEMM_STAGGER") ? atoi(getenv("STTRAN_GEMM_STAGGER")) : 1;
+  static const int env_stagger = exp_env("STTRAN_GEMM_STAGGER") ? atoi(exp_env("STTRAN_GEMM_STAGGER")) : 1;
   const int half = (env_stagger && sp.G > num_cus()) ? std::max(num_cus(), sp.G / 2) : sp.G;
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg,
                      sp.g_sk, base, rem, half, slab, epi);

@@ -30,6 +30,19 @@ struct DeviceMarks {
 };
 int num_cus();   // compute units of the current device (cached per ordinal)
 
+// Tuning / A-B knobs come from the environment in EXPERIMENT builds only (make EXTRA=-DSTTRAN_GEMM_EXPERIMENT: what
+// tools/gemm_bench.py and tools/experiments/ use).  The product library reads NO environment variable on the forward path
+// (the one exception, STTRAN_GUARD_WORKSPACE, switches the test allocator of tests/test_guarded_buffers_gpu.py and is
+// read once, at the first allocation).
+inline const char* exp_env(const char* name) {
+#ifdef STTRAN_GEMM_EXPERIMENT
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // ---- GEMM ------------------------------------------------------------------------------
 // tiles of gemm_f32_mfma.h (ids are part of the sttran_debug_gemm test hook: keep them stable)
 // 5: gemm_f32_t16.h (16x16x4 MFMA blocks; N % 176 == 0, padded operands, vector epilogue only)

@@ -8,8 +8,10 @@ using T256x128 = GemmTile<256, 128, 4, 2>;   // 8 waves, wave tile 64x64
 using T128x128 = GemmTile<128, 128, 2, 2>;   // 4 waves, wave tile 64x64
 using T128x64 = GemmTile<128, 64, 2, 2>;     // 4 waves, wave tile 64x32
 using T64x64 = GemmTile<64, 64, 2, 2>;       // 4 waves, wave tile 32x32
+#ifdef STTRAN_GEMM_EXPERIMENT
 using TConv2 = GemmTile<256, 128, 4, 2, B_CONV2>;   // conv3x3 as implicit GEMM: all 256 output channels in one tile (B gathered once)
 using TUnionFlat = GemmTile<256, 128, 4, 2, B_UNION_FLAT>;   // all 256 channels in one tile, columns = pair * 49 + hw
+#endif
 
 int num_cus() {
   static int cus[kMaxDevices] = {};
@@ -24,14 +26,14 @@ int num_cus() {
 
 // below this many rows the planner keeps the 32x32x2 tiles (small-M launches are latency-bound: measured in
 // tools/gemm_bench.py --shapes path16 / path16x8)
-static const int64_t kT16MinRows = getenv("STTRAN_T16_MIN_ROWS") ? atoll(getenv("STTRAN_T16_MIN_ROWS")) : 1024;
+static const int64_t kT16MinRows = exp_env("STTRAN_T16_MIN_ROWS") ? atoll(exp_env("STTRAN_T16_MIN_ROWS")) : 1024;
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int force_tile, int force_split) {
   (void)force_split;   // split-K is subsumed by the stream-K schedule
   GemmPlan best{TILE_128x128, 1};
   double best_t = 1e300;
   const int64_t ksteps = (K + kBK - 1) / kBK;
-  static const int env_tile = getenv("STTRAN_GEMM_TILE") ? atoi(getenv("STTRAN_GEMM_TILE")) : 0;   // experiments only
+  static const int env_tile = exp_env("STTRAN_GEMM_TILE") ? atoi(exp_env("STTRAN_GEMM_TILE")) : 0;   // experiments only
   if (!force_tile && env_tile > 0 && env_tile < TILE_COUNT) force_tile = env_tile;
   if (force_tile < 0 || force_tile >= TILE_COUNT || force_tile == TILE_RETIRED_6) force_tile = 0;
   for (int t = 1; t < TILE_COUNT; ++t) {
@@ -113,6 +115,7 @@ hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B,
   // N = 26: only the 64x64 tile makes sense (sttran_api.hip forces it); padded operands
   return launch_tile<GemmTile<64, 64, 2, 2, B_KMAJOR_PAD>, EpiScalar4<EpiHeads>>(s, TILE_64x64, A, B, M, N, K, slab, EpiScalar4<EpiHeads>{epi});
 }
+#ifdef STTRAN_GEMM_EXPERIMENT   // round 2's 32x32x2 forms of the two convolutions: A/B runs only (STTRAN_CONV_ENGINE=32x32)
 // union_func1: M = 256 out channels (A = W[256][K], one M-tile), N = 49 P columns (pair, hw) read in place from the
 // NCHW tensor (B_UNION_FLAT), hybrid data-parallel + stream-K schedule like every other GEMM
 hipError_t launch_union_conv(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
@@ -132,6 +135,8 @@ hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, co
   GemmOperand B{c2, 0, nullptr, 0};
   return launch_tile<TConv2, EpiConvRelBn>(s, TILE_256x128, A, B, 256, P * 49, 1152, slab, epi);
 }
+
+#endif
 
 // ---- calibration: back-to-back v_mfma_f32_32x32x2_f32 on independent accumulators, no memory ----
 // Gives the fp32-MFMA rate THIS device sustains (clock under load differs between MI355X boards by

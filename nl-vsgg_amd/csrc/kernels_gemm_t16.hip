@@ -56,7 +56,7 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
   if (split && !slab) return hipErrorInvalidValue;
   // N-tiles per group of the tile order (consecutive tile indices sweep `half` N-tiles of one M-tile, then the next M-tile):
   // the 64 workgroups of an XCD hold a (64 / half) x half block of tiles whose panels they share through its L2
-  static const int env_gn = getenv("STTRAN_T16_GROUP_N") ? atoi(getenv("STTRAN_T16_GROUP_N")) : 0;
+  static const int env_gn = exp_env("STTRAN_T16_GROUP_N") ? atoi(exp_env("STTRAN_T16_GROUP_N")) : 0;
   const int half = env_gn > 0 ? env_gn : T::GROUP_N;
   const Epi e{epi};
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,

@@ -1087,7 +1087,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
   const bool is_dsg = c.model == STTRAN_MODEL_DSG_DETR;
   // DSG-DETR builds its class sequences on the device (no read-back, cacheable, capturable); STTRAN_DSG_HOST_LAYOUT=1
   // takes round 1's host builder instead, which reads labels / pair_idx back on every call (kept for A/B tests).
-  static const bool dsg_host_env = getenv("STTRAN_DSG_HOST_LAYOUT") && atoi(getenv("STTRAN_DSG_HOST_LAYOUT")) != 0;
+  static const bool dsg_host_env = exp_env("STTRAN_DSG_HOST_LAYOUT") && atoi(exp_env("STTRAN_DSG_HOST_LAYOUT")) != 0;   // experiment builds only
   const bool dsg_dev = is_dsg && !dsg_host_env;
   const bool host_dsg = is_dsg && !dsg_dev;
   if (host_dsg || !(P == h->L->cached_P && counts == h->L->cached_counts && clips == h->L->cached_clips && h->L->lay.dsg_device == dsg_dev)) {
@@ -1226,7 +1226,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                        epi_plain(X0 + 512, LD, W(h, "obj_fc.bias"))))) return rc;
   // the two convolutions on the 16x16x4 kernel structure (gemm_f32_t16c.h); STTRAN_CONV_ENGINE=32x32 keeps round 2's
   // gemm_sk_kernel<B_UNION_FLAT / B_CONV2> for A/B runs
-  static const bool conv_t16 = !(getenv("STTRAN_CONV_ENGINE") && std::string(getenv("STTRAN_CONV_ENGINE")) == "32x32");
+  static const bool conv_t16 = !(exp_env("STTRAN_CONV_ENGINE") && std::string(exp_env("STTRAN_CONV_ENGINE")) == "32x32");   // experiment builds only
   {
     // conv stack of the spatial masks (lib/sttran.py:337-345), both convolutions as implicit GEMMs
     {
@@ -1248,8 +1248,12 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                                  h->L->slab.as<float>()));
     else if (conv_t16)
       HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->L->slab.as<float>()));
+#ifdef STTRAN_GEMM_EXPERIMENT
     else
       HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->L->slab.as<float>()));
+#else
+    (void)e2;
+#endif
   }
   {
     const Tensor& wu = h->w["union_func1.weight"];
@@ -1265,9 +1269,11 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
     else if (conv_t16)
       HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                                   h->L->slab.as<float>()));
+#ifdef STTRAN_GEMM_EXPERIMENT
     else
       HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                               h->L->slab.as<float>()));
+#endif
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
                        epi_plain(X0 + 1024, LD, W(h, "vr_fc.bias"))))) return rc;
@@ -1553,7 +1559,7 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
   }
   // the planes are re-made on every call (a freed W may come back at the same address with other contents) unless the
   // caller vouches for W staying put: STTRAN_X3_CACHE_PLANES=1 (tools/gemm_bench.py times the GEMM alone that way)
-  static const bool cache_ok = getenv("STTRAN_X3_CACHE_PLANES") && atoi(getenv("STTRAN_X3_CACHE_PLANES")) != 0;
+  static const bool cache_ok = exp_env("STTRAN_X3_CACHE_PLANES") && atoi(exp_env("STTRAN_X3_CACHE_PLANES")) != 0;   // experiment builds only
   if (!cache_ok || cached_w != Wt || cached_n != N || cached_k != K) {
     if (split_planes(s, Wt, ldw, (int)N, (int)K, planes, ldp) != hipSuccess) return STTRAN_ERR_HIP;
     cached_w = Wt; cached_n = N; cached_k = K;
