@@ -11,6 +11,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsttran_hip.so")
+# A/B runs of tools/ only (an experiment build, or the previous commit's library next to the current one): another build
+# of the SAME library, e.g. STTRAN_LIB=nl-vsgg_amd/csrc/ab/libsttran_hip_A.so.  Still this package's HIP library -- there
+# is no other implementation to select.
+if os.environ.get("STTRAN_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["STTRAN_LIB"])
 
 STTRAN_OK = 0
 STTRAN_ERR_INVALID = 1

@@ -264,9 +264,12 @@ __device__ __forceinline__ void epi_linear_strip(const EpiLinear& e, int row, co
 // (out-proj, FFN2) and bias + per-slot position bias (QKV of the middle decoder layers, encoder QKV with neither).  The
 // bias strip is shared by the two rows, so the operands are 3 NV vectors next to the 2 NV accumulators.  Returns false
 // (nothing done) for the forms it does not cover: output scatter (out_rowidx / out_rowidx2), residual AND position bias.
-template <int NV>
+// NA = column groups of the accumulator array, [J0, J0 + NV) = the groups this call handles (group j starts at column
+// col0 + 16 j): the 176-column tile runs it on two halves of its row so that the operand set stays below the registers
+// the kernel has left next to 88 accumulator registers (one more load -> store phase per tile, no scratch traffic).
+template <int NA, int J0, int NV>
 __device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (&rows)[2], const bool (&valid)[2],
-                                                 const int (&cols)[NV], const f32x4 (&acc)[2][NV]) {
+                                                 int col0, const f32x4 (&acc)[2][NA]) {
   const bool hrb = e.rowbias != nullptr, hrs = e.res != nullptr;
   if (e.out_rowidx || e.out_rowidx2 || (hrb && hrs) || e.scale) return false;
   const bool hb = e.bias != nullptr;
@@ -280,15 +283,16 @@ __device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (
                  : hrb ? e.rowbias + (int)e.rowslot[r] * e.rb_ld : nullptr;
   }
   const int rbmax = e.rb_cols - 4;
+  const int c0 = col0 + 16 * J0;
   if (hb) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) b[j] = *reinterpret_cast<const f32x4*>(e.bias + cols[j]);
+    for (int j = 0; j < NV; ++j) b[j] = *reinterpret_cast<const f32x4*>(e.bias + c0 + 16 * j);
   }
   if (hrs || hrb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NV; ++j) x[i][j] = *reinterpret_cast<const f32x4*>(src[i] + (hrb ? min(cols[j], rbmax) : cols[j]));
+      for (int j = 0; j < NV; ++j) x[i][j] = *reinterpret_cast<const f32x4*>(src[i] + (hrb ? min(c0 + 16 * j, rbmax) : c0 + 16 * j));
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -296,10 +300,10 @@ __device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (
     float* dst = e.C + (int64_t)rows[i] * e.ldc;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      f32x4 w = hb ? acc[i][j] + b[j] : acc[i][j];
+      f32x4 w = hb ? acc[i][J0 + j] + b[j] : acc[i][J0 + j];
       if (hrb) {
         const f32x4 w2 = w + x[i][j];
-        const bool in = cols[j] < e.rb_cols;
+        const bool in = c0 + 16 * j < e.rb_cols;
 #pragma unroll
         for (int c = 0; c < 4; ++c) w[c] = in ? w2[c] : w[c];
       }
@@ -308,7 +312,7 @@ __device__ __forceinline__ bool epi_linear_rows2(const EpiLinear& e, const int (
         for (int c = 0; c < 4; ++c) w[c] = relu_nan(w[c]);
       }
       if (hrs) w += x[i][j];
-      *reinterpret_cast<f32x4*>(dst + cols[j]) = w;
+      *reinterpret_cast<f32x4*>(dst + c0 + 16 * j) = w;
     }
   }
   return true;

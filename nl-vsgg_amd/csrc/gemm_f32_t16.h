@@ -281,13 +281,17 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
       // 176-column tile has no registers for a whole row's operands next to its 88 accumulator registers (it spills):
       // its rows go in two halves (measured: 140.2 vs 138.2 TFLOP/s on [21120,1936,1936] + residual; the 128-column
       // tile gains 1 % from whole rows)
-      int colsall[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) colsall[j] = col0 + 16 * j;
       const int rows2[2] = {row0, row0 + 16};
       const bool valid2[2] = {row0 < M, row0 + 16 < M};
-      // the common forms (bias + residual, bias + position bias, bias only): both rows in one load -> store phase
-      if (epi_linear_rows2<NB>(epi.e, rows2, valid2, colsall, acc)) {
+      // the common forms (bias + residual, bias + position bias, bias only): both rows in one load -> store phase (the
+      // 128-column tile), or in two -- columns [0, 96) and [96, 176) -- on the 176-column tile, whose 88 accumulator
+      // registers leave no room for a whole row pair's operands (33 vectors: the kernel spilled 24 registers around them)
+      constexpr int H0R = NB <= 8 ? NB : (NB + 1) / 2;
+      bool done = epi_linear_rows2<NB, 0, H0R>(epi.e, rows2, valid2, col0, acc);
+      if constexpr (H0R < NB) {
+        if (done) epi_linear_rows2<NB, H0R, NB - H0R>(epi.e, rows2, valid2, col0, acc);
+      }
+      if (done) {
       } else if constexpr (NB <= 8) {
         int cols[NB];
 #pragma unroll
