@@ -38,10 +38,16 @@ __device__ __forceinline__ int argmax_masked(const float* __restrict__ row, int 
   return bi;
 }
 
-// frame f owns input rows [fstart[f], fstart[f+1]) (boxes are sorted by frame id, as the detector emits them)
-__global__ void objcls_frame_ranges_kernel(const float* __restrict__ boxes, int B, int T, int* __restrict__ fstart) {
+// frame f owns input rows [fstart[f], fstart[f+1]) (boxes are sorted by frame id, as the detector emits them).
+// `status` was written by objcls_check_order_kernel, launched in front of this kernel on the same stream: on unsorted
+// input (value 2 set) the binary search below would give non-monotone ranges, so every frame is made EMPTY instead --
+// the kernels behind this one (expand, NMS, row / pair writers) then loop over nothing, and the host returns
+// STTRAN_ERR_ORDER without looking at their outputs (the Python wrapper sorts the rows and calls again).
+__global__ void objcls_frame_ranges_kernel(const float* __restrict__ boxes, int B, int T, int* __restrict__ fstart,
+                                           const int* __restrict__ status) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f > T) return;
+  if (*status & 2) { fstart[f] = 0; return; }
   int lo = 0, hi = B;                       // first row whose frame id >= f
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -51,7 +57,7 @@ __global__ void objcls_frame_ranges_kernel(const float* __restrict__ boxes, int 
 }
 
 // The frame ranges above need the rows sorted by frame id, every id inside [0, T) (the reference selects rows with
-// `boxes[:, 0] == i` and accepts any order, lib/sttran.py:59-62,205-207): checked here, status bit 1 otherwise
+// `boxes[:, 0] == i` and accepts any order, lib/sttran.py:59-62,205-207): checked here; status |= 2 (bit 1) otherwise
 __global__ void objcls_check_order_kernel(const float* __restrict__ boxes, int B, int T, int* __restrict__ status) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B) return;
@@ -400,7 +406,7 @@ hipError_t launch_objcls_select(hipStream_t s, const float* boxes, const float* 
   if (e != hipSuccess) return e;
   const int tb = 128, tg = (T + 1 + tb - 1) / tb;
   hipLaunchKernelGGL(objcls_check_order_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, boxes, (int)B, T, totals + 2);
-  hipLaunchKernelGGL(objcls_frame_ranges_kernel, dim3(tg), dim3(tb), 0, s, boxes, (int)B, T, fstart);
+  hipLaunchKernelGGL(objcls_frame_ranges_kernel, dim3(tg), dim3(tb), 0, s, boxes, (int)B, T, fstart, totals + 2);
   hipLaunchKernelGGL(objcls_expand_kernel, dim3(tg), dim3(tb), 0, s, dist, labels, ncol, T, fstart, ent_src, ent_mask, ent_label, n1);
   hipLaunchKernelGGL(objcls_nms_kernel, dim3(T), dim3(256), 0, s, boxes, dist, ncol, fstart, ent_src, ent_mask, n1, thr, ge, kept,
                      n2, big_f, big_i, big_b);
