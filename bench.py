@@ -72,7 +72,7 @@ SHAPES = {"16x12": (16, 12, 64), "64x36": (64, 36, 4)}
 # calls in flight in the one-clip-per-pass leg.  3 lanes + the caller's stream = the 4 hardware queues a HIP process gets by
 # default (GPU_MAX_HW_QUEUES): measured 2 / 3 / 4 / 6 / 8 lanes = 18.8 / 20.9 / 18.8 / 18.5 / 20.3 k frames/s on a box whose
 # serial rate was 14.4 k (tools/experiments/lanes_probe.py --api) -- more lanes than queues share queues again
-ONE_CLIP_LANES = 3
+ONE_CLIP_LANES = {"16x12": 3, "64x36": 2}        # (64x36: 2 lanes 9.88-9.94 k, 4 lanes 9.64-10.0 k, serial 9.26-9.34 k frames/s)
 SWEEP_CPS = {"16x12": 16, "64x36": 1}                           # the smaller batch of `batch_sweep` (round 1-2 defaults)
 
 
@@ -647,16 +647,17 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
         dt_serial = timed(loop_serial, n1)
-        model.lanes = ONE_CLIP_LANES
+        nlanes = ONE_CLIP_LANES[workload]
+        model.lanes = nlanes
         model.reserve(int(ones[0]["pair_idx"].shape[0]) + 8, int(ones[0]["features"].shape[0]) + 8)
         dt1 = timed(loop_lanes, 2 * n1)
         model.sync_check()
         model.lanes = 1
         res["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1, "calls": 2 * n1,
-                                    "lanes": ONE_CLIP_LANES, "serial": {"value": T / dt_serial, "ms_per_step": 1e3 * dt_serial},
+                                    "lanes": nlanes, "serial": {"value": T / dt_serial, "ms_per_step": 1e3 * dt_serial},
                                     "note": "same clip shape with clips_per_step = 1: the reference's batch "
                                             "(dataloader/wk_action_genome.py:622-627), a different entry on every call, "
-                                            f"{ONE_CLIP_LANES} calls in flight on the handle's lanes (forward_async / join); "
+                                            f"{nlanes} calls in flight on the handle's lanes (forward_async / join); "
                                             "`serial` = one call at a time on the caller's stream"}
 
     # ---- the batch size between one clip and the default (the default of rounds 1-2): a few steps, not `value` ---
