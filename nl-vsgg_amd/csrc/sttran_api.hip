@@ -58,7 +58,10 @@ struct DevBuf {
       if (e != hipSuccess) return e;
     }
     bytes = need;
-    return hipMemset(p, 0, need);
+    // hipMemset of device memory is asynchronous (it runs in the NULL stream) and a lane's own stream is non-blocking:
+    // nothing orders it against the kernels the caller is about to enqueue there -- wait for it here (growth is rare)
+    hipError_t e = hipMemset(p, 0, need);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
   }
   hipError_t drop() {
     hipError_t e = hipSuccess;
@@ -606,6 +609,10 @@ int lane_create(SttranHandle* h, Lane** out) {
       hipEventCreateWithFlags(&L->done_ev, hipEventDisableTiming) != hipSuccess) {
     delete L;
     return fail(h, STTRAN_ERR_HIP, "lane: stream / event / flag allocation failed");
+  }
+  if (hipDeviceSynchronize() != hipSuccess) {            // the memset above ran in the NULL stream; L->own does not wait for it
+    lane_destroy(L);
+    return fail(h, STTRAN_ERR_HIP, "lane: synchronise failed");
   }
   *out = L;
   return STTRAN_OK;
@@ -1412,7 +1419,7 @@ int sttran_sync_check(SttranHandle* h, void* stream) {
   for (Lane* L : h->lanes) {
     int f = 0;
     HIPCK(hipMemcpy(&f, L->err_flag, 4, hipMemcpyDeviceToHost));
-    if (f) HIPCK(hipMemset(L->err_flag, 0, 4));
+    if (f) { HIPCK(hipMemset(L->err_flag, 0, 4)); HIPCK(hipDeviceSynchronize()); }
     flag |= f;
   }
   if (flag) {

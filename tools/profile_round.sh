@@ -59,5 +59,8 @@ python3 tools/ag_split_bench.py > "$O/${P}_ag_split_shaped.json" 2>/dev/null
 # two ranks on this one GPU over gloo (the N > 1 code path, self-launched): what the 8-GPU driver run will execute
 BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline \
   --detail "$O/${P}_bench_2ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
-ls "$O" | grep "^${P}_" | grep -v "_kt_\|_pmc_[a-z0-9]*_[A-Z]" | head -60
+# raw rocprofv3 output is scratch: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf "$O/${P}"_kt_*/ "$O/${P}"_pmc_*_[A-Z]*/
+find "$O" -maxdepth 1 -name "${P}_pmc_*_[A-Z]*.err" -size -1k -delete
+ls "$O" | grep "^${P}_" | head -80
 du -sh "$O"
