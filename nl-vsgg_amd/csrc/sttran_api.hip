@@ -601,6 +601,7 @@ void build_layout_dsg_static(const std::vector<int32_t>& counts, const std::vect
 }
 
 // ---- lanes ---------------------------------------------------------------------------------------
+void lane_destroy(Lane* L);
 int lane_create(SttranHandle* h, Lane** out) {
   Lane* L = new Lane();
   if (hipMalloc(reinterpret_cast<void**>(&L->err_flag), 64) != hipSuccess || hipMemset(L->err_flag, 0, 64) != hipSuccess ||
