@@ -163,3 +163,27 @@ def test_lane_argument_errors(weights):
     assert lib.sttran_lane_join(h, -1, None) == 0         # nothing in flight: a no-op
     with pytest.raises(ValueError):
         m.lanes = 0
+
+
+def test_first_calls_of_fresh_lanes_see_initialised_buffers(weights):
+    """A lane's workspace, chunk table and index staging are allocated (and zeroed) inside its FIRST forward.  hipMemset runs
+    in the NULL stream, which the lane's non-blocking stream does not follow: round 4 shipped a version whose zeroing could
+    land after the chunk table's upload (an intermittent GPU fault on address nil, 1 run in ~8 of the one-clip bench leg).
+    Fresh handles, no reserve(), lanes used at once -- every result must equal the classic forward's."""
+    e_small = syn.make_entry(21, [3, 1, 4, 2, 2])
+    e_big = syn.make_entry(22, [11] * 16)
+    ref = _model("predcls", weights)
+    want = {}
+    for name, e in (("small", e_small), ("big", e_big)):
+        p = ref(_cuda_entry(e))
+        want[name] = {k: p[k].clone() for k in OUT_KEYS}
+    torch.cuda.synchronize()
+    for rep in range(6):
+        m = _model("predcls", weights)
+        m.lanes = 3
+        preds = [(n, m.forward_async(_cuda_entry(e))) for n, e in (("small", e_small), ("big", e_big), ("small", e_small),
+                                                                     ("big", e_big), ("big", e_big), ("small", e_small))]
+        m.sync_check()
+        for n, p in preds:
+            assert all(torch.equal(p[k], want[n][k]) for k in OUT_KEYS), (rep, n)
+        m._destroy()
