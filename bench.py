@@ -483,7 +483,7 @@ def by_kernel_tables(entries, forwards):
 
 
 def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=False, roofline=True, one_clip=False,
-                 pcie=False, repeats=1, alone=False, rotate=True):
+                 pcie=False, repeats=1, alone=False, rotate=True, same_batch=True):
     """Warm-up, EXACTLY `steps` timed steps between barrier + synchronize (max over ranks), then the optional legs."""
     world, device, dist = env.world, env.device, env.dist
     T, N, _ = SHAPES[workload]
@@ -570,7 +570,7 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
                                     "alternate, so build_layout and both staged uploads run inside every timed step")
                                    if len(batches) > 1 else "hit (one batch re-forwarded)"},
     }
-    if len(batches) > 1 and world == 1 and not graph:
+    if len(batches) > 1 and world == 1 and not graph and same_batch:
         # the loop of rounds 1-3 for comparison: ONE batch re-forwarded, so the index-map and chunk-table caches hit
         for _ in range(2):
             forward_batch(0)
@@ -983,7 +983,7 @@ def main():
     pcie = "full" if args.pcie else ("overlapped" if extras and world == 1 and not args.no_pcie and not args.graph else False)
     main_res = run_workload(env, model, args.model, args.workload, cps, args.steps, args.warmup, graph=args.graph,
                             roofline=not args.no_roofline, one_clip=extras, pcie=pcie, repeats=args.repeats,
-                            alone=extras, rotate=not args.graph)
+                            alone=extras, rotate=not args.graph, same_batch=not args.profile_only_batch)
     result = {
         "metric": "frames/sec (PredCls inference)" if args.model == "sttran" else "frames/sec (SGDet inference, DSG-DETR)",
         "value": main_res["value"], "unit": "frames/s",
