@@ -7,7 +7,9 @@
  *
  * With <out2.bin> the program also forwards a BATCH of two clips handed over as per-clip pointer tables (SttranInputs
  * form 2: nothing concatenated, every clip's pair_idx local to the clip) -- here the same clip twice, which is the
- * cheapest way to own two clips -- and writes the 2 P rows of that call.
+ * cheapest way to own two clips -- and writes the 2 P rows of that call; then it runs the clip on two LANES of the handle
+ * (sttran_set_lanes / sttran_forward_lane / sttran_lane_join: two calls in flight on the handle's own streams) and checks
+ * in C that both results equal the classic call's bit for bit.
  *
  * weights.bin : int32 n, then n x { int32 keylen, key bytes, int32 ndim, int64 shape[ndim], float data[] }
  * entry.bin   : int32 mode, int64 B, int64 P, int32 T, int32 frame_counts[T], float features[B*2048],
@@ -190,6 +192,37 @@ int main(int argc, char** argv) {
     printf("two clips by pointer: %lld pairs -> %s\n", (long long)(2 * P), argv[4]);
     hipFree(att2); hipFree(spa2); hipFree(con2);
     free(counts2);
+
+    /* ---- lanes: the reference's loop forwards one clip per call; two such calls in flight on the handle's own streams.
+     *      Each lane call is forked from `stream` (no wait there); the consumer joins before it reads. ---- */
+    CHECK(sttran_set_lanes(h, 2));
+    float* lo[2][3];
+    SttranOutputs outl[2];
+    for (int l = 0; l < 2; ++l) {
+      for (int i = 0; i < 3; ++i) HIPCHECK(hipMalloc((void**)&lo[l][i], no[i] * 4));
+      memset(&outl[l], 0, sizeof outl[l]);
+      outl[l].struct_size = sizeof outl[l];
+      outl[l].attention_distribution = lo[l][0]; outl[l].spatial_distribution = lo[l][1]; outl[l].contacting_distribution = lo[l][2];
+    }
+    for (int rep = 0; rep < 3; ++rep)
+      for (int l = 0; l < 2; ++l) CHECK(sttran_forward_lane(h, l, &in, &outl[l], stream));
+    CHECK(sttran_lane_join(h, -1, stream));          /* `stream` now waits for both lanes ... */
+    CHECK(sttran_sync_check(h, stream));             /* ... and the host for `stream` */
+    int same = 1;
+    for (int l = 0; l < 2 && same; ++l)
+      for (int i = 0; i < 3 && same; ++i) {
+        float* a = (float*)malloc(no[i] * 4 + 4);
+        float* b = (float*)malloc(no[i] * 4 + 4);
+        if (!a || !b) return 1;
+        HIPCHECK(hipMemcpy(a, dsrc[i], no[i] * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b, lo[l][i], no[i] * 4, hipMemcpyDeviceToHost));
+        same = memcmp(a, b, no[i] * 4) == 0;
+        free(a); free(b);
+      }
+    printf("lanes: %d lanes, results %s the classic forward\n", (int)sttran_num_lanes(h), same ? "identical to" : "DIFFER from");
+    for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < 3; ++i) hipFree(lo[l][i]);
+    if (!same) return 3;
   }
 
   sttran_destroy(h);

@@ -64,6 +64,8 @@ def test_c_host_matches_python_shim(tmp_path):
     o2path = str(tmp_path / "out2.bin")
     r = subprocess.run([exe, wpath, epath, opath, o2path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
+    # the example also ran the clip on two lanes of the handle and compared, in C, with its classic call
+    assert "lanes: 2 lanes, results identical to the classic forward" in r.stdout, r.stdout
     got = np.fromfile(opath, dtype=np.float32)
     assert got.size == P * 26
     att, spa, con = got[:P * 3].reshape(P, 3), got[P * 3:P * 9].reshape(P, 6), got[P * 9:].reshape(P, 17)
