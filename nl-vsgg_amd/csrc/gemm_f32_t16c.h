@@ -39,7 +39,10 @@ struct Tile16C {
   static_assert(BKIND == B_UNION_FLAT || BKIND == B_CONV2, "convolution operand kinds only");
 };
 
-template <class T, class Epi>
+// ABL (experiment builds, STTRAN_T16C_ABLATE; timing only, wrong results): 1 = no column-operand (B) global loads in the
+// loop, 2 = no weight (A) loads, 3 = no loads at all, 4 = no loads and no ds_writes, 5 = no barrier, 6 = accumulators start
+// from zero (no V read at the tile start), 7 = no epilogue stores
+template <class T, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(T::NT, 2)
 gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
                int g_sk, int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
@@ -146,7 +149,7 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     f32x4 acc[2][NB];
     const int ch0 = m0 + wave * 32 + 4 * fg;
     const int colb = n0 + fr;
-    if constexpr (EpiInit<Epi>::value) {
+    if constexpr (EpiInit<Epi>::value && ABL != 6) {
       if (ks0 == 0) {
         // C += A B: the K range that starts a tile accumulates onto the output's old values (64 independent loads,
         // in flight with the first operand loads)
@@ -210,15 +213,16 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       for (int sb = 0; sb < NBLK; ++sb) {
         if (sb + 1 < NBLK) read_b(cur, sb + 1);
         if (sb == NB - 3) read_a(cur, 1);
-        if (sb < NLS) load_slot(set, sb, t + 2);
-        if (sb >= NBLK - NP) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
+        constexpr bool kLoadB = ABL != 1 && ABL != 3 && ABL != 4, kLoadA = ABL != 2 && ABL != 3 && ABL != 4, kStore = ABL != 4;
+        if (sb < NLS && (sb < AV ? kLoadA : kLoadB)) load_slot(set, sb, t + 2);
+        if (sb >= NBLK - NP && kStore) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
         if (sb + 1 < NBLK) {
           mma_block(sb);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (sb < NLS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          if (sb >= NBLK - NP) {
+          if (sb < NLS && (sb < AV ? kLoadA : kLoadB)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (sb >= NBLK - NP && kStore) {
             if constexpr (!UFLAT) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           }
@@ -230,7 +234,7 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      if (ABL != 5) __syncthreads();
       read_a(nxt, 0);
       read_b(nxt, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -256,7 +260,7 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int col = colb + 16 * j;
-        if (col < N) {
+        if (col < N && (ABL != 7 || acc[0][j][0] == 12345.678f)) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -9,6 +9,23 @@ static hipError_t launch_t16c(hipStream_t s, const GemmOperand& A, const GemmOpe
                               const Epi& epi) {
   static DeviceMarks marks;
   auto kern = gemm16c_kernel<T, Epi>;
+#ifdef STTRAN_GEMM_EXPERIMENT
+  {
+    static DeviceMarks m[8];
+    const int abl = exp_env("STTRAN_T16C_ABLATE") ? atoi(exp_env("STTRAN_T16C_ABLATE")) : 0;
+    switch (abl) {
+      case 1: kern = gemm16c_kernel<T, Epi, 1>; break;
+      case 2: kern = gemm16c_kernel<T, Epi, 2>; break;
+      case 3: kern = gemm16c_kernel<T, Epi, 3>; break;
+      case 4: kern = gemm16c_kernel<T, Epi, 4>; break;
+      case 5: kern = gemm16c_kernel<T, Epi, 5>; break;
+      case 6: kern = gemm16c_kernel<T, Epi, 6>; break;
+      case 7: kern = gemm16c_kernel<T, Epi, 7>; break;
+      default: break;
+    }
+    if (abl >= 1 && abl <= 7 && m[abl].raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown;
+  }
+#endif
   {
     hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES);
     if (e != hipSuccess) return e;
