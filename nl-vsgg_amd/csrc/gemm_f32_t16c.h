@@ -41,7 +41,8 @@ struct Tile16C {
 
 // ABL (experiment builds, STTRAN_T16C_ABLATE; timing only, wrong results): 1 = no column-operand (B) global loads in the
 // loop, 2 = no weight (A) loads, 3 = no loads at all, 4 = no loads and no ds_writes, 5 = no barrier, 6 = accumulators start
-// from zero (no V read at the tile start), 7 = no epilogue stores
+// from zero (no V read at the tile start), 7 = no epilogue stores, 8 = the B loads are issued but nothing waits for them
+// (they land in registers the ds_writes do not read): separates their issue / bandwidth cost from their latency
 template <class T, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(T::NT, 2)
 gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
@@ -113,24 +114,33 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       }
     }
     f32x4 ra[2][AV], rb[2][BV];
+    f32x4 rbx[2][BV];                                          // ABL 8 only
+    (void)rbx;
     bool zb[2][BV];                                            // CONV2: the piece is a zero piece (tap outside the image)
     (void)zb;
     auto kstep_of = [&](int step) { return ks0 + (step < nsteps ? step : 0); };   // steps past the end re-read step 0 (unused)
     // load slot n of a K-step: AV weight pieces, then the column pieces (a UNION piece is four dword loads, each its own slot)
+    // LOAD order (round 4, union conv only): the column operand first, the weights last -- union_feat comes from HBM, the
+    // weights are 2 MB that every tile re-reads from L2; the column pieces get a quarter of a K-step more time in flight:
+    // 4 246 vs 4 270 us in situ (conv3x3, whose gathered operand is cache-resident, lost 0.6 % with it and keeps the old
+    // order).  Slot m of the K-step loads piece n = (m + AV) mod NLS.
     constexpr int NLS = AV + (UFLAT ? 4 * BV : BV);
-    auto load_slot = [&](int set, int n, int step) {
+    auto load_slot = [&](int set, int m, int step) {
       const int ks = kstep_of(step);
+      const int n = !UFLAT ? m : (m < NLS - AV ? m + AV : m - (NLS - AV));
       if (n < AV) {
         ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)((ks - ks0) * kBK * 4)));
       } else if constexpr (UFLAT) {
         const int i = (n - AV) >> 2, e = (n - AV) & 3;
-        rb[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
+        if constexpr (ABL == 8) rbx[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
+        else rb[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
       } else {
         const int i = n - AV;
         const int k0 = ks * kBK, tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH, ci0 = k0 - tap * Geo::CIN;
         const int iy = cy[i] + ky, ix = cx[i] + kx;
         const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
-        rb[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
+        if constexpr (ABL == 8) rbx[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
+        else rb[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
         zb[set][i] = !ok;
       }
     };
@@ -214,14 +224,14 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         if (sb + 1 < NBLK) read_b(cur, sb + 1);
         if (sb == NB - 3) read_a(cur, 1);
         constexpr bool kLoadB = ABL != 1 && ABL != 3 && ABL != 4, kLoadA = ABL != 2 && ABL != 3 && ABL != 4, kStore = ABL != 4;
-        if (sb < NLS && (sb < AV ? kLoadA : kLoadB)) load_slot(set, sb, t + 2);
+        if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) load_slot(set, sb, t + 2);
         if (sb >= NBLK - NP && kStore) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
         if (sb + 1 < NBLK) {
           mma_block(sb);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (sb < NLS && (sb < AV ? kLoadA : kLoadB)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           if (sb >= NBLK - NP && kStore) {
             if constexpr (!UFLAT) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -250,6 +260,10 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
     }
 
+    if constexpr (ABL == 8) {
+#pragma unroll
+      for (int i = 0; i < BV; ++i) asm volatile("" ::"v"(rbx[0][i]), "v"(rbx[1][i]));
+    }
     if (nsteps == ksteps) {
       // whole tile: per-channel constants first (8 channels per lane), then only stores
       typename Epi::Consts cst[2][4];

@@ -11,7 +11,7 @@ static hipError_t launch_t16c(hipStream_t s, const GemmOperand& A, const GemmOpe
   auto kern = gemm16c_kernel<T, Epi>;
 #ifdef STTRAN_GEMM_EXPERIMENT
   {
-    static DeviceMarks m[8];
+    static DeviceMarks m[9];
     const int abl = exp_env("STTRAN_T16C_ABLATE") ? atoi(exp_env("STTRAN_T16C_ABLATE")) : 0;
     switch (abl) {
       case 1: kern = gemm16c_kernel<T, Epi, 1>; break;
@@ -21,9 +21,10 @@ static hipError_t launch_t16c(hipStream_t s, const GemmOperand& A, const GemmOpe
       case 5: kern = gemm16c_kernel<T, Epi, 5>; break;
       case 6: kern = gemm16c_kernel<T, Epi, 6>; break;
       case 7: kern = gemm16c_kernel<T, Epi, 7>; break;
+      case 8: kern = gemm16c_kernel<T, Epi, 8>; break;
       default: break;
     }
-    if (abl >= 1 && abl <= 7 && m[abl].raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown;
+    if (abl >= 1 && abl <= 8 && m[abl].raise_lds(reinterpret_cast<const void*>(kern), T::LDS_BYTES) != hipSuccess) return hipErrorUnknown;
   }
 #endif
   {

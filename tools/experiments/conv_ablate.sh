@@ -3,7 +3,7 @@
 # given as $1), STTRAN_T16C_ABLATE = 0..7 (gemm_f32_t16c.h: timing-only variants, wrong results), mean microseconds of the two
 # kernels in situ from bench.py's per-kernel table (HIP events around every launch).
 LIB=${1:?path of an experiment build of libsttran_hip.so}
-for a in 0 1 2 3 4 5 6 7 0; do
+for a in ${ABLATIONS:-0 1 2 3 4 5 6 7 8 0}; do
   STTRAN_LIB=$LIB STTRAN_T16C_ABLATE=$a python3 bench.py --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-extra-workloads 2>&1 >/dev/null \
     | grep "^BENCH_DETAIL" | cut -c14- | python3 -c "
 import json,sys
