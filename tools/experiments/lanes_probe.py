@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--lanes", default="1,2,3,4")
     ap.add_argument("--calls", type=int, default=200)
     ap.add_argument("--workload", default="16x12")
+    ap.add_argument("--pack", type=int, default=1, help="--api: clips per call (pack_clips(copy=False)); 1 = single clips")
     ap.add_argument("--api", action="store_true", help="ONE handle with `model.lanes = K` (forward_async / join) instead of K handles")
     ap.add_argument("--join", default="lag", choices=["lag", "end"], help="--api: join call i - K + 1 after submitting call i, or only at the end")
     a = ap.parse_args()
@@ -38,13 +39,19 @@ def main():
                    enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", is_wks=True, feat_dim=2048).to(dev)
         m.eval(); m.check_indices = False
         m.load_state_dict(sd, strict=False)
+        packs = [[bench.device_clip(T, N, gen, dev, shifted=(j == 0 and b == 1)) for j in range(a.pack)] for b in range(2)] if a.pack > 1 else None
         for lanes in [int(x) for x in a.lanes.split(",")]:
             m.lanes = lanes
 
             def run(n):
                 pending = collections.deque()
                 for i in range(n):
-                    pending.append(m.forward_async(dict(clips[i % len(clips)])))
+                    if a.pack > 1:
+                        from nl_vsgg_amd.lib.sttran import pack_clips
+                        entry = pack_clips(packs[i % len(packs)], copy=False)
+                    else:
+                        entry = dict(clips[i % len(clips)])
+                    pending.append(m.forward_async(entry))
                     if a.join == "lag" and len(pending) == lanes:
                         m.join(pending.popleft())
                 m.join()
@@ -55,7 +62,7 @@ def main():
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            print(f"api lanes {lanes} join={a.join}: {1e3 * (t2 - t0) / a.calls:.3f} ms/clip  {a.calls * T / (t2 - t0):.0f} frames/s   "
+            print(f"api lanes {lanes} join={a.join} pack={a.pack}: {1e3 * (t2 - t0) / a.calls:.3f} ms/call  {a.calls * a.pack * T / (t2 - t0):.0f} frames/s   "
                   f"(host enqueue {1e3 * (t1 - t0) / a.calls:.3f} ms/clip)", flush=True)
         return
     for lanes in [int(x) for x in a.lanes.split(",")]:
