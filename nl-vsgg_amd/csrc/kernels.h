@@ -58,6 +58,8 @@ size_t gemm_slab_bytes();        // what a `slab` argument must point to
 // padded: both operands can be read up to ceil32(K) columns per row and B is zero there (gemm_f32_mfma.h, B_KMAJOR_PAD)
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                        const EpiLinear& epi, GemmPlan plan, float* slab, int padded);
+// the tile gemm_linear really launches for these operands (plan.tile, or TILE_256x128 when a 16x16x4 tile's contract is not met)
+int gemm_effective_tile(const GemmOperand& A, const GemmOperand& B, int N, int K, const EpiLinear& epi, GemmPlan plan, int padded);
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab);
 hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, const EpiConvRelBn& epi, int P,

@@ -86,6 +86,22 @@ static bool epi_vectorizable(const EpiLinear& e, int N) {
          (e.ldres & 3) == 0;
 }
 
+// The tile a launch really runs on: the planner's choice, unless that is a 16x16x4 tile whose contract the operands or the
+// epilogue do not meet (gathered-by-offset rows, a per-column affine, a gathered operand of unknown span, ...): then the
+// general 32x32x2 engine's 256 x 128 tile.  (The per-launch profile records are labelled with THIS tile.)
+int gemm_effective_tile(const GemmOperand& A, const GemmOperand& B, int N, int K, const EpiLinear& epi, GemmPlan plan, int padded) {
+  if (plan.tile != TILE_128x176 && plan.tile != TILE_T128x128) return plan.tile;
+  // gemm16_kernel addresses by (64-bit tile base + 32-bit in-tile byte offset): any operand size, as long as one tile's
+  // rows stay inside 4 GB (ld < 2^21 floats); a GATHERED A has no tile base -- its rows must be known to lie within 4 GB
+  // of A.ptr (GemmOperand::span; unknown = the general engine, which carries 64-bit pointers)
+  const int64_t kLim = (int64_t)1 << 32;
+  const bool a_ok = A.rowidx ? (A.span > 0 && (A.span * A.ld + ((K + 31) / 32) * 32) * 4 < kLim) : (129 * A.ld * 4 < kLim);
+  const bool b_ok = !B.rowidx && !B.rowoff && 177 * B.ld * 4 < kLim;
+  const bool ok = padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff &&
+                  aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) && (B.ld & 3) == 0 && a_ok && b_ok;
+  return ok ? plan.tile : TILE_256x128;
+}
+
 // padded != 0: the operands meet the B_KMAJOR_PAD contract (gemm_f32_mfma.h); rows must then be 128-byte multiples apart
 // only as far as the caller's ld says -- what matters is that ceil32(K) columns of every row are readable.
 hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
@@ -94,15 +110,7 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
   // swapped MFMA ports; 16-byte vector epilogue when every pointer allows it, else the same kernel with scalar stores
   // (arbitrary caller tensors -- the select path of sttran_debug_gemm -- always take the scalar form)
   if (plan.tile == TILE_128x176 || plan.tile == TILE_T128x128) {
-    // gemm16_kernel addresses by (64-bit tile base + 32-bit in-tile byte offset): any operand size, as long as one tile's
-    // rows stay inside 4 GB (ld < 2^21 floats); a GATHERED A has no tile base -- its rows must be known to lie within 4 GB
-    // of A.ptr (GemmOperand::span; unknown = the general engine, which carries 64-bit pointers)
-    const int64_t kLim = (int64_t)1 << 32;
-    const bool a_ok = A.rowidx ? (A.span > 0 && (A.span * A.ld + ((K + 31) / 32) * 32) * 4 < kLim) : (129 * A.ld * 4 < kLim);
-    const bool b_ok = !B.rowidx && !B.rowoff && 177 * B.ld * 4 < kLim;
-    if (padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff && aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) &&
-        (B.ld & 3) == 0 && a_ok && b_ok)
-      return gemm_linear_t16(s, A, B, M, N, K, epi, slab, plan.tile);
+    if (gemm_effective_tile(A, B, N, K, epi, plan, padded) == plan.tile) return gemm_linear_t16(s, A, B, M, N, K, epi, slab, plan.tile);
     plan.tile = TILE_256x128;                          // contract not met: the general engine
   }
   if (!padded) return gemm_linear_sel(s, A, B, M, N, K, epi, plan, slab);

@@ -344,10 +344,11 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     }
   }
   GemmOperand B{Wt, pad32(K), nullptr, 0};               // every weight that comes here is stored padded (Tensor::ld)
-  const bool t16 = plan.tile == TILE_128x176 || plan.tile == TILE_T128x128;
+  const int tile = gemm_effective_tile(A, B, N, K, epi, plan, 1);        // the label names the kernel that really runs
+  const bool t16 = tile == TILE_128x176 || tile == TILE_T128x128;
   ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
-               t16 ? std::string("gemm16_kernel<Tile16<") + tile_name(plan.tile) + ">,EpiLinear>"
-                   : std::string("gemm_sk_kernel<GemmTile<") + tile_name(plan.tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
+               t16 ? std::string("gemm16_kernel<Tile16<") + tile_name(tile) + ">,EpiLinear>"
+                   : std::string("gemm_sk_kernel<GemmTile<") + tile_name(tile) + ",B_KMAJOR_PAD>,EpiLinear>", M, N, K);
   HIPCK(gemm_linear(s, A, B, M, N, K, epi, plan, h->L->slab.as<float>(), 1));
   return STTRAN_OK;
 }
