@@ -41,7 +41,9 @@ struct GemmOperand {
   const float* ptr;
   int64_t ld;          // row stride in floats (multiple of 4, 16-byte aligned base)
   const int* rowidx;   // optional gather: logical row r reads physical row rowidx[r]
-  int aux;             // B_UNION_FLAT: number of pairs P (ld = pair stride K*49)
+  int aux;             // B operand, B_UNION_FLAT: number of pairs P (ld = pair stride K*49).  A operand with rowoff: column
+                       // split of a GROUPED launch -- output columns >= aux read their rows through rowoff + M (a second
+                       // gather table behind the first: subj_fc | obj_fc as one GEMM over stacked weights); 0 = none
   // Optional gather by ELEMENT OFFSET: logical row r (B_UNION_FLAT: pair r) starts at ptr + rowoff[r] floats.  This is
   // how a batch of clips is read where the caller left it (SttranInputs' per-clip pointer tables): the rows of one
   // operand then live in several allocations, `ptr` is the first clip's tensor and an offset may be any signed
@@ -480,8 +482,10 @@ gemm_sk_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     for (int i = 0; i < AV; ++i) {
       const int g = m0 + (tid >> 3) + i * (NT >> 3);
       va[i] = g < M;
-      pa[i] = A.ptr + (A.rowoff ? (va[i] ? A.rowoff[g] : (int64_t)0)
-                                : (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + kq4;
+      const int64_t* ro = A.rowoff;
+      if (ro && A.aux > 0 && n0 >= A.aux) ro += M;           // grouped launch: the second column group's gather table
+      pa[i] = A.ptr + (ro ? (va[i] ? ro[g] : (int64_t)0)
+                          : (int64_t)(va[i] ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + kq4;
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {

@@ -158,6 +158,7 @@ struct SttranHandle {
   DevBuf derived;               // one arena for all derived tensors
   float *bn1_scale = nullptr, *bn1_shift = nullptr, *bn2_scale = nullptr, *bn2_shift = nullptr;
   float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
+  float *fc_w = nullptr, *fc_b = nullptr;   // [subj_fc ; obj_fc] stacked: weights [1024, feat_dim], bias [1024] (one grouped launch)
   void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
@@ -753,7 +754,8 @@ int sttran_finalize_weights(SttranHandle* h) {
   const int nh = c.attention_classes + c.spatial_classes + c.contact_classes;
   const bool oc = c.mode != STTRAN_MODE_PREDCLS;
   // arena layout (floats)
-  size_t total = 2 * 128 + 2 * 256 + 128 * 104 + 256 * 1152 + (size_t)nh * pad32(D) + 128 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64;
+  size_t total = 2 * 128 + 2 * 256 + 128 * 104 + 256 * 1152 + (size_t)nh * pad32(D) + 128 + (size_t)c.dec_layers * 4 * D + 2 * 4 + 2 * 1024 + 64 +
+                 (size_t)1024 * pad32(c.feat_dim) + 1024 + 64;
   HIPCK(h->derived.ensure(total * 4));
   float* p = h->derived.as<float>();
   auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~size_t(3); return r; };
@@ -766,6 +768,16 @@ int sttran_finalize_weights(SttranHandle* h) {
   for (int i = 0; i < c.dec_layers; ++i) h->dec[i].posbias = take(4 * D);
   h->oc_pos_scale = take(4); h->oc_pos_shift = take(4);
   h->oc_bn_scale = take(1024); h->oc_bn_shift = take(1024);
+  h->fc_w = take((size_t)1024 * pad32(c.feat_dim) + 64); h->fc_b = take(1024);
+  // subj_fc and obj_fc (lib/sttran.py:346-347, 390-391) as ONE grouped GEMM: stacked weight rows / biases; the two column
+  // groups gather their A rows through two tables (GemmOperand::aux)
+  {
+    const size_t wb = (size_t)512 * pad32(c.feat_dim) * 4;
+    HIPCK(hipMemcpy(h->fc_w, W(h, "subj_fc.weight"), wb, hipMemcpyDeviceToDevice));
+    HIPCK(hipMemcpy(h->fc_w + (size_t)512 * pad32(c.feat_dim), W(h, "obj_fc.weight"), wb, hipMemcpyDeviceToDevice));
+    HIPCK(hipMemcpy(h->fc_b, W(h, "subj_fc.bias"), 512 * 4, hipMemcpyDeviceToDevice));
+    HIPCK(hipMemcpy(h->fc_b + 512, W(h, "obj_fc.bias"), 512 * 4, hipMemcpyDeviceToDevice));
+  }
 
   // eval-mode BatchNorm -> per-channel scale/shift: y = x*s + t, s = g/sqrt(var+eps), t = b - mean*s
   auto bn = [&](const std::string& pre, int n, float* ds, float* dt) -> int {
@@ -1229,10 +1241,10 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                             h->L->err_flag, L.max_dec));
   }
   // subject / object rows of `features` gathered by element offset (one chunk per clip: GemmOperand::rowoff)
-  if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off}, W(h, "subj_fc.weight"), (int)P, 512, FD,
-                       epi_plain(X0, LD, W(h, "subj_fc.bias"))))) return rc;
-  if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 0, feat_off + P}, W(h, "obj_fc.weight"), (int)P, 512, FD,
-                       epi_plain(X0 + 512, LD, W(h, "obj_fc.bias"))))) return rc;
+  // subj_fc | obj_fc in ONE launch: N = 1024 over the stacked weights, columns >= 512 read their rows
+  // through the second gather table (feat_off + P); X0 columns [0, 512) and [512, 1024) are adjacent
+  if ((rc = run_linear(h, s, GemmOperand{feat_base, FD, nullptr, 512, feat_off}, h->fc_w, (int)P, 1024, FD,
+                       epi_plain(X0, LD, h->fc_b)))) return rc;
   // the two convolutions on the 16x16x4 kernel structure (gemm_f32_t16c.h); STTRAN_CONV_ENGINE=32x32 keeps round 2's
   // gemm_sk_kernel<B_UNION_FLAT / B_CONV2> for A/B runs
   static const bool conv_t16 = !(exp_env("STTRAN_CONV_ENGINE") && std::string(exp_env("STTRAN_CONV_ENGINE")) == "32x32");   // experiment builds only
