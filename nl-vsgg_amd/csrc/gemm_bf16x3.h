@@ -186,8 +186,10 @@ gemm_x3_kernel(GemmOperand A, X3Weights B, int M, int N, int K, int tiles_m, int
       } else {
         const int row = (tid >> 3) + i * (NT >> 3);
         const int g = m0 + row;
-        pa[i] = A.ptr + (A.rowoff ? (g < M ? A.rowoff[g] : (int64_t)0)
-                                  : (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + ks0 * kBK + (tid & 7) * 4;
+        const int64_t* ro = A.rowoff;
+        if (ro && A.aux > 0 && n0 >= A.aux) ro += M;         // grouped launch (GemmOperand::aux): second gather table
+        pa[i] = A.ptr + (ro ? (g < M ? ro[g] : (int64_t)0)
+                            : (int64_t)(g < M ? (A.rowidx ? A.rowidx[g] : g) : 0) * A.ld) + ks0 * kBK + (tid & 7) * 4;
         wa[i] = row * 64 + ((a_c ^ ((row >> 2) & 3)) * 16) + a_half * 8;
       }
     }

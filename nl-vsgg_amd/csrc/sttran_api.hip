@@ -160,6 +160,7 @@ struct SttranHandle {
   float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
   float *fc_w = nullptr, *fc_b = nullptr;   // [subj_fc ; obj_fc] stacked: weights [1024, feat_dim], bias [1024] (one grouped launch)
   void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
+  void* fc_planes = nullptr;    // ... [3][1024][feat_dim] planes of the stacked subj_fc | obj_fc weight
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<DecLayer> dec;
   std::vector<Lane*> lanes;     // >= 1
@@ -329,6 +330,13 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
   }
   if (h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && (M >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL) &&
       N >= 128 && !force_tile) {
+    if (Wt == h->fc_w && h->fc_planes) {               // the grouped subj_fc | obj_fc launch (a derived tensor, not in h->w)
+      const int64_t ldf = pad32(K);
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
+                   "gemm_x3_kernel<X3Tile<256,128,4,2>,EpiLinear>", M, N, K);
+      HIPCK(gemm_linear_x3(s, A, h->fc_planes, ldf, (int64_t)1024 * ldf, M, N, K, epi, h->L->slab.as<float>()));
+      return STTRAN_OK;
+    }
     // the weight (or a row range of it: the last decoder layer projects k|v and q separately) as bf16 planes
     for (auto& kv : h->w) {
       const Tensor& t = kv.second;
@@ -688,6 +696,7 @@ void sttran_destroy(SttranHandle* h) {
     if (kv.second.planes) hipFree(kv.second.planes);
   }
   if (h->w4_planes) hipFree(h->w4_planes);
+  if (h->fc_planes) hipFree(h->fc_planes);
   h->derived.release();
   for (Lane* L : h->lanes) lane_destroy(L);
   for (auto& e : h->prof_ev) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -1046,6 +1055,11 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
         if (!t.planes) HIPCK(hipMalloc(&t.planes, (size_t)3 * 256 * FDp * 2 + 256));
         HIPCK(split_planes(s, t.d, FDp, 256, (int)FDp, t.planes, FDp));
       }
+    }
+    if (h->fc_w) {      // stacked subj_fc | obj_fc weight of the grouped launch
+      const int64_t ldf = pad32(c.feat_dim);
+      if (!h->fc_planes) HIPCK(hipMalloc(&h->fc_planes, (size_t)3 * 1024 * ldf * 2 + 256));
+      HIPCK(split_planes(s, h->fc_w, ldf, 1024, c.feat_dim, h->fc_planes, ldf));
     }
     if (h->w4_perm) {   // conv3x3 weight in its (ky, kx, ci) K order
       if (!h->w4_planes) HIPCK(hipMalloc(&h->w4_planes, (size_t)3 * 256 * 1152 * 2 + 256));
