@@ -33,6 +33,11 @@ namespace sttran {
 // phase clocks of the 128 x 176 kernel (experiment builds, STTRAN_T16_ABLATE=9): summed over workgroups, s_memtime ticks
 // [0] prologue (tile start -> first MFMA), [1] main loop, [2] epilogue / parking, [3] tiles, [4] K-steps
 __device__ unsigned long long g_t16_clk[8];
+// STTRAN_T16_SKEW (experiment): start-up skew of the workgroups that share operand panels inside an XCD, in units of
+// s_sleep(16) ~ 1 024 clocks: workgroup blk sleeps ((blk & 7) + ((blk >> 3) & 7)) * skew units before its first tile, so that
+// the 8 sharers of an A panel (consecutive blk) and the 8 sharers of a W panel (blk 8 apart) ask for a line ~0.4 us apart
+// instead of within the same microsecond.  Tests the hit-on-miss explanation of the GEMM class's fabric reads.
+__device__ int g_t16_skew;
 #endif
 
 template <int BM_, int BN_>
@@ -89,6 +94,12 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
   // no faster, 140.3-141.0 vs 141.8-142.1 TFLOP/s, and 2.3 x the fabric reads, 3.3 vs 1.4 GB per [21120,1936,1936]
   // launch (rocprofv3 FETCH_SIZE), because workgroups that drift apart stop sharing panels.)
   const int pre_end = rg.begin;
+#ifdef STTRAN_GEMM_EXPERIMENT
+  if (g_t16_skew > 0) {
+    const int units = ((blk & 7) + ((blk >> 3) & 7)) * g_t16_skew;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
 
   int dp_done = 0;
   for (int it = rg.begin; dp_done < dp_per_wg || it < rg.end;) {

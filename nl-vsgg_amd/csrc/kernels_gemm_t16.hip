@@ -33,6 +33,16 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
   }
 #ifdef STTRAN_GEMM_EXPERIMENT
   {
+    static int skew_set = -1;
+    const int skew = getenv("STTRAN_T16_SKEW") ? atoi(getenv("STTRAN_T16_SKEW")) : 0;
+    if (skew != skew_set) {
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_t16_skew), &skew, sizeof(int)) != hipSuccess) return hipErrorUnknown;
+      skew_set = skew;
+    }
+  }
+#endif
+#ifdef STTRAN_GEMM_EXPERIMENT
+  {
     static bool once = false;
     if (!once && getenv("STTRAN_T16_OCC")) {
       once = true;
