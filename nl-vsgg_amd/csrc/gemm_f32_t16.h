@@ -38,6 +38,11 @@ __device__ unsigned long long g_t16_clk[8];
 // the 8 sharers of an A panel (consecutive blk) and the 8 sharers of a W panel (blk 8 apart) ask for a line ~0.4 us apart
 // instead of within the same microsecond.  Tests the hit-on-miss explanation of the GEMM class's fabric reads.
 __device__ int g_t16_skew;
+// ABL == 9 trace ("what does the resident partner do during the other's epilogue?"): one record of 8
+// 64-bit words per tile segment -- HW_ID, XCC_ID, blk, tile, and the four s_memtime stamps (tile start, first MFMA, last
+// MFMA, epilogue stores acknowledged) -- into a caller buffer (sttran_debug_t16_trace); 100 MHz chip-wide clock
+__device__ unsigned long long* g_t16_trace;
+__device__ unsigned int g_t16_trace_cap, g_t16_trace_n;
 #endif
 
 template <int BM_, int BN_>
@@ -349,6 +354,16 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
       if (tid == 0) {
         atomicAdd(&g_t16_clk[0], clk1 - clk0); atomicAdd(&g_t16_clk[1], clk2 - clk1); atomicAdd(&g_t16_clk[2], clk3 - clk2);
         atomicAdd(&g_t16_clk[3], 1ull); atomicAdd(&g_t16_clk[4], (unsigned long long)nsteps);
+        if (g_t16_trace) {
+          const unsigned int r = atomicAdd(&g_t16_trace_n, 1u);
+          if (r < g_t16_trace_cap) {
+            unsigned long long* rec = g_t16_trace + (size_t)r * 8;
+            rec[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            rec[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+            rec[2] = (unsigned long long)blk; rec[3] = ((unsigned long long)nsteps << 32) | (unsigned int)tile;
+            rec[4] = clk0; rec[5] = clk1; rec[6] = clk2; rec[7] = clk3;
+          }
+        }
       }
     }
 #endif

@@ -85,6 +85,20 @@ hipError_t gemm_linear_t16(hipStream_t s, const GemmOperand& A, const GemmOperan
 }
 
 #ifdef STTRAN_GEMM_EXPERIMENT
+// trace buffer of the ABL == 9 build (tools/experiments/t16_trace.py): buf = device memory for cap records of 8 uint64, or NULL
+extern "C" int sttran_debug_t16_trace(unsigned long long* buf, unsigned int cap) {
+  const unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_t16_trace), &buf, sizeof(buf)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_t16_trace_cap), &cap, sizeof(cap)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_t16_trace_n), &zero, sizeof(zero)) != hipSuccess)
+    return 2;
+  return 0;
+}
+extern "C" int sttran_debug_t16_trace_count(unsigned int* n) {
+  return hipMemcpyFromSymbol(n, HIP_SYMBOL(g_t16_trace_n), sizeof(unsigned int)) == hipSuccess ? 0 : 2;
+}
+#endif
+#ifdef STTRAN_GEMM_EXPERIMENT
 // reads and clears the phase clocks (tools/gemm_bench.py --phases)
 extern "C" int sttran_debug_t16_clocks(unsigned long long* out8) {
   unsigned long long z[8] = {};
