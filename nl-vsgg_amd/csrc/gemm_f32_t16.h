@@ -64,7 +64,10 @@ struct Tile16 {
 
 // ABL: timing-only ablations for tools/gemm_bench.py (wrong results): 1 = no global loads in the loop, 2 = no global
 // loads and no ds_writes, 3 = no barrier, 4 = all of them (LDS reads + MFMAs only), 5 = loads but no ds_writes
-template <class T, class Epi, int ABL = 0>
+// ROWOFF (round 4; the 128 x 128 tile only -- it has the registers): the A rows are gathered by 64-bit ELEMENT offsets
+// (GemmOperand::rowoff: the feature rows of a batch handed over as per-clip pointer tables live in several allocations),
+// one 64-bit pointer per staged piece instead of a 32-bit offset; GemmOperand::aux = the column split of a grouped launch.
+template <class T, class Epi, int ABL = 0, bool ROWOFF = false>
 __global__ void __launch_bounds__(T::NT, 2)
 gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
               int g_sk, int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
@@ -145,13 +148,27 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
 #pragma unroll
     for (int i = 0; i < BV; ++i) ob[i] = (uint32_t)(((int64_t)brow(i) * B.ld + schunk * 4 + ks0 * kBK) * 4);
     const char* const abase = reinterpret_cast<const char*>(A.ptr) + (gathered ? (int64_t)0 : (int64_t)m0 * A.ld * 4);
+    const char* pa64[ROWOFF ? AV : 1];
+    if constexpr (ROWOFF) {
+      const int64_t* ro = A.rowoff;
+      if (A.aux > 0 && n0 >= A.aux) ro += M;                 // grouped launch: the second column group's gather table
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int g = m0 + srow + RPR * i;
+        pa64[i] = reinterpret_cast<const char*>(A.ptr + ro[g < M ? g : m0] + schunk * 4 + ks0 * kBK);   // rows past M: the tile's first row
+      }
+    }
+    (void)pa64;
     const char* const bbase = reinterpret_cast<const char*>(B.ptr) + (int64_t)n0 * B.ld * 4;
     // two register sets: the global loads of K-step u go to set u & 1, TWO steps ahead of their use (issued during step
     // u - 2, written to LDS during step u - 1), so a load has more than a whole K-step (~5 us) to arrive from HBM
     f32x4 ra[2][AV], rb[2][BV];
     auto koff = [&](int step) { return (step < nsteps ? step : 0) * kBK; };   // steps past the end re-read step 0 (never used)
     auto load_piece = [&](int set, int n, int ko) {
-      if (n < AV) ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)ko * 4u));
+      if (n < AV) {
+        if constexpr (ROWOFF) ra[set][n] = *reinterpret_cast<const f32x4*>(pa64[n] + (uint32_t)ko * 4u);
+        else ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)ko * 4u));
+      }
       else rb[set][n - AV] = *reinterpret_cast<const f32x4*>(bbase + (ob[n - AV] + (uint32_t)ko * 4u));
     };
     auto store_piece = [&](int set, int n, float* stage) {

@@ -97,7 +97,10 @@ int gemm_effective_tile(const GemmOperand& A, const GemmOperand& B, int N, int K
   const int64_t kLim = (int64_t)1 << 32;
   const bool a_ok = A.rowidx ? (A.span > 0 && (A.span * A.ld + ((K + 31) / 32) * 32) * 4 < kLim) : (129 * A.ld * 4 < kLim);
   const bool b_ok = !B.rowidx && !B.rowoff && 177 * B.ld * 4 < kLim;
-  const bool ok = padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && !A.rowoff &&
+  // rows gathered by element offset (rowoff): the 128 x 128 tile has a 64-bit-pointer form (K % 32 == 0: a gathered caller
+  // tensor has no zero padding behind its rows), the 176-column tile does not
+  const bool ro_ok = !A.rowoff || (plan.tile == TILE_T128x128 && !A.rowidx && K % 32 == 0 && (A.aux == 0 || A.aux % 128 == 0));
+  const bool ok = padded && N % (plan.tile == TILE_T128x128 ? 128 : 176) == 0 && epi_vectorizable(epi, N) && !epi.scale && ro_ok &&
                   aligned16(A.ptr) && (A.ld & 3) == 0 && aligned16(B.ptr) && (B.ld & 3) == 0 && a_ok && b_ok;
   return ok ? plan.tile : TILE_256x128;
 }

@@ -6,14 +6,14 @@
 
 namespace sttran {
 
-template <class T, int TILE_ID>
+template <class T, int TILE_ID, bool ROWOFF = false>
 static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                              const EpiLinear& epi, float* slab) {
   using Epi = EpiLinearV;
   if (M <= 0 || N <= 0) return hipSuccess;
-  if (N % T::BN != 0) return hipErrorInvalidValue;
+  if (N % T::BN != 0 || (ROWOFF != (A.rowoff != nullptr))) return hipErrorInvalidValue;
   static DeviceMarks marks;
-  auto kern = gemm16_kernel<T, Epi>;
+  auto kern = gemm16_kernel<T, Epi, 0, ROWOFF>;
 #ifdef STTRAN_GEMM_EXPERIMENT
   {
     static DeviceMarks m1, m2, m3, m4, m5, m9;
@@ -28,7 +28,7 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
   }
 #endif
   {
-    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(gemm16_kernel<T, Epi>), T::LDS_BYTES);
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(gemm16_kernel<T, Epi, 0, ROWOFF>), T::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
 #ifdef STTRAN_GEMM_EXPERIMENT
@@ -80,6 +80,7 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
 
 hipError_t gemm_linear_t16(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                            const EpiLinear& epi, float* slab, int tile) {
+  if (tile == TILE_T128x128 && A.rowoff) return launch_t16<Tile16<128, 128>, TILE_T128x128, true>(s, A, B, M, N, K, epi, slab);
   if (tile == TILE_T128x128) return launch_t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, epi, slab);
   return launch_t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, epi, slab);
 }
