@@ -889,8 +889,16 @@ def compact_line(d):
                                              "traffic_measured_in_run", "algorithmic_bytes_per_launch", "launches_per_step",
                                              "avg_launch_us", "share_of_device_time")}
         out["roofline"]["kernel"] = "fp32-MFMA GEMM class (gemm16 / gemm16c / gemm_sk kernels + fix-up launches)"
-        out["roofline"]["dominant"] = r.get("dominant")
-        out["roofline"]["per_class_ms_per_step"] = _r(r["per_class_ms_per_step"], 3)
+        # FLAT scalars only: the driver's parsed record keeps one level of scalars under `roofline` / `cpu_baseline` and
+        # drops nested dicts (BENCH_r04.json lost `dominant{}`), so the dominant kernel's row and the per-class times of
+        # one step are spelled out as `dominant_*` / `ms_*` keys; the nested tables live in the detail file
+        dom = r.get("dominant") or {}
+        for src, dst in (("name", "dominant_kernel"), ("frac", "dominant_frac"), ("tflops", "dominant_tflops"),
+                         ("mean_us", "dominant_mean_us"), ("launches_per_step", "dominant_launches_per_step"),
+                         ("gflop_per_step", "dominant_gflop_per_step"), ("share_of_device_time", "dominant_share_of_device_time")):
+            out["roofline"][dst] = dom.get(src)
+        for cls in ("gemm", "union_conv", "mask_conv", "attention", "layernorm", "index"):
+            out["roofline"]["ms_" + cls] = _r(float(r["per_class_ms_per_step"].get(cls, 0.0)), 4)
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "host_cores": c["host_cores"],

@@ -12,19 +12,52 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 COMPACT_LIMIT = 4096          # the driver keeps the last 8 KB of stdout: the whole line must be in it
 
 
-def _check_compact(d):
+DOMINANT_KEYS = ("dominant_kernel", "dominant_frac", "dominant_tflops", "dominant_mean_us", "dominant_launches_per_step",
+                 "dominant_gflop_per_step")
+CLASS_MS_KEYS = ("ms_gemm", "ms_union_conv", "ms_mask_conv", "ms_attention", "ms_layernorm")
+
+
+def driver_filter(d):
+    """What the driver's `parsed` record keeps of the stdout line (read off BENCH_r04.json): the contract keys; of the
+    dicts among them (`config`, `roofline`, `cpu_baseline`) ONE level of scalars, strings cut at 120 characters, nested
+    dicts / lists dropped; every other top-level key only by name under `extra_keys`."""
+    out = {}
+    for k in CONTRACT:
+        if k not in d:
+            continue
+        v = d[k]
+        if isinstance(v, dict):
+            v = {kk: (vv[:120] if isinstance(vv, str) else vv) for kk, vv in v.items() if not isinstance(vv, (dict, list))}
+        out[k] = v
+    out["extra_keys"] = sorted(k for k in d if k not in CONTRACT)
+    return out
+
+
+def _check_compact(d, dominant=True, driver_record=False):
     for k in CONTRACT:
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "dominant"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.0 < r["frac"] < 1.0 and r["peak"] == 157.3
-    dom = r["dominant"]
-    assert dom["tflops"] > 0 and 0.0 < dom["frac"] < 1.0 and dom["launches_per_step"] >= 1 and dom["mean_us"] > 0
+    # nothing nested under the two dicts the driver flattens: a nested value would be dropped from its record
+    for blk in ("roofline", "cpu_baseline"):
+        assert not any(isinstance(v, (dict, list)) for v in d[blk].values()), blk
+    if dominant:
+        for k in DOMINANT_KEYS + CLASS_MS_KEYS:
+            assert k in r, k
+        assert "gemm" in r["dominant_kernel"]
+        assert r["dominant_tflops"] > 0 and 0.0 < r["dominant_frac"] < 1.0 and r["dominant_launches_per_step"] >= 1
+        assert r["dominant_mean_us"] > 0 and r["dominant_gflop_per_step"] > 0
+        assert abs(r["dominant_frac"] - r["dominant_tflops"] / r["peak"]) < 1e-6
+        # the dominant kernel's row is consistent with itself and fits into the step
+        t_dom_ms = r["dominant_launches_per_step"] * r["dominant_mean_us"] * 1e-3
+        assert abs(r["dominant_gflop_per_step"] / t_dom_ms - r["dominant_tflops"]) < 1e-3 * r["dominant_tflops"]
+        assert t_dom_ms <= 1.05 * r["ms_gemm"] + 1e-9 and r["ms_gemm"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -53,7 +86,11 @@ def test_committed_bench_line_has_the_contract_fields():
     raw = open(os.path.join(ROOT, "profiles", lines[-1])).read()
     assert len(raw.strip().splitlines()) == 1 and len(raw.strip()) < COMPACT_LIMIT
     d = json.loads(raw)
-    _check_compact(d)
+    flat = not lines[-1].startswith("r4_")                  # round 4's lines carry the nested roofline.dominant{} form
+    if not flat:
+        d["roofline"] = {k: v for k, v in d["roofline"].items() if not isinstance(v, dict)}
+    _check_compact(d, dominant=flat)
+    _check_compact(driver_filter(d), dominant=flat)         # ... and survives what the driver keeps of it
     assert d["n_gpus"] == 1 and d["one_clip_per_pass"]["value"] > 0 and d["workloads"]["64x36"]["value"] > 0
     assert d["config"]["layout_cache"].startswith("miss") and d["pcie_inclusive_overlapped"]["value"] > 0
     det = json.load(open(os.path.join(ROOT, "profiles", lines[-1].replace("bench_default_with_cpu", "bench_default_detail"))))
@@ -84,7 +121,8 @@ def test_compact_line_stays_under_the_driver_capture():
                       "algorithmic_bytes_per_launch": 431937565.09090906, "launches_per_step": 22.0, "avg_launch_us": 1100.2403279834173,
                       "share_of_device_time": 0.8087984440710084, "kernel": "k" * 400,
                       "dominant": {"name": "gemm16_kernel<Tile16<128,176>,EpiLinear>", "launches_per_step": 13.0, "mean_us": 1290.123456,
-                                   "gflop_per_step": 2381.8123456, "tflops": 142.0123456, "frac": 0.90123456, "share_of_device_time": 0.55123456},
+                                   "gflop_per_step": 2381.8123456, "tflops": 2381.8123456 / (13.0 * 1290.123456e-3),
+                                   "frac": 2381.8123456 / (13.0 * 1290.123456e-3) / 157.3, "share_of_device_time": 0.55123456},
                       "per_class_ms_per_step": {"gemm": 24.205123, "union_conv": 4.264123, "mask_conv": 0.667123, "attention": 0.541123,
                                                 "layernorm": 0.233123, "index": 0.018123},
                       "by_kernel": [{"kernel": "k" * 80}] * 12, "by_shape": [{"kernel": "k" * 80}] * 21},
@@ -100,6 +138,10 @@ def test_compact_line_stays_under_the_driver_capture():
     assert "\n" not in line and len(line) < COMPACT_LIMIT, len(line)
     c = json.loads(line)
     _check_compact(c)
+    # the driver's own record of this line (scalars one level below the contract dicts) still carries the dominant kernel
+    f = driver_filter(c)
+    _check_compact(f)
+    assert f["roofline"]["dominant_kernel"] == "gemm16_kernel<Tile16<128,176>,EpiLinear>" and f["roofline"]["ms_mask_conv"] > 0
     assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
     assert c["strong_scaling"]["ag_split_shaped"]["eval_s_rank0"] > 0 and c["workloads"]["64x36"]["value"] > 0
 
@@ -129,4 +171,7 @@ def test_newest_driver_bench_line_has_the_contract_fields():
     if os.path.basename(files[-1]) == "BENCH_r03.json" and not d:
         pytest.xfail("BENCH_r03.json: the round-3 line (26 KB) exceeded the driver's capture; fixed by compact_line (round 4)")
     assert rec.get("rc", 0) == 0 and d, files[-1]
-    _check_compact(d)
+    # BENCH_r04.json: bench.py nested the dominant kernel's row as roofline.dominant{} and the driver's record keeps scalars
+    # only, so that record has no dominant row; since round 5 the row is flat `dominant_*` scalars
+    # and every later record must carry it
+    _check_compact(d, dominant=os.path.basename(files[-1]) > "BENCH_r04.json")
