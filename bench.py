@@ -73,6 +73,9 @@ SHAPES = {"16x12": (16, 12, 64), "64x36": (64, 36, 4)}
 # default (GPU_MAX_HW_QUEUES): measured 2 / 3 / 4 / 6 / 8 lanes = 18.8 / 20.9 / 18.8 / 18.5 / 20.3 k frames/s on a box whose
 # serial rate was 14.4 k (tools/experiments/lanes_probe.py --api) -- more lanes than queues share queues again
 ONE_CLIP_LANES = {"16x12": 3, "64x36": 2}        # (64x36: 2 lanes 9.88-9.94 k, 4 lanes 9.64-10.0 k, serial 9.26-9.34 k frames/s)
+# entries per coalesced group of the one-clip-per-pass leg (`model.coalesce`): the reference's loop body unchanged, K calls
+# issued as one by-pointer forward on the next lane
+ONE_CLIP_COALESCE = {"16x12": 16, "64x36": 4}
 SWEEP_CPS = {"16x12": 16, "64x36": 1}                           # the smaller batch of `batch_sweep` (round 1-2 defaults)
 
 
@@ -669,13 +672,52 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
         model.reserve(int(ones[0]["pair_idx"].shape[0]) + 8, int(ones[0]["features"].shape[0]) + 8)
         dt1 = timed(loop_lanes, 2 * n1)
         model.sync_check()
+        # (c) COALESCED: the same loop body -- `pending.append(model.forward_async(entry))` / `model.join(pred)` -- with
+        # `model.coalesce = K`: every K calls are issued as ONE by-pointer forward on the next lane and each entry gets its
+        # rows as views; the caller only keeps `model.pipeline_depth` (= lanes x K) entries un-joined instead of `lanes`
+        K = ONE_CLIP_COALESCE[workload]
+        model.coalesce = K
+        model.reserve(K * int(ones[0]["pair_idx"].shape[0]) + 8, K * int(ones[0]["features"].shape[0]) + 8)
+
+        def loop_coalesced(n, hints=True):
+            pending = collections.deque()
+            for i in range(n):
+                e = dict(ones[i % len(ones)])
+                if not hints:                              # the reference's entry: no host-side frame counts
+                    e.pop("frame_counts"); e.pop("num_frames")
+                pending.append(model.forward_async(e))
+                if len(pending) == model.pipeline_depth:
+                    model.join(pending.popleft())
+            while pending:
+                model.join(pending.popleft())
+        n_co = K * nlanes * max(4, min(steps, 20) // 2)
+        loop_coalesced(2 * K * nlanes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop_coalesced(n_co)
+        torch.cuda.synchronize()
+        dt_co = (time.perf_counter() - t0) / n_co
+        loop_coalesced(K * nlanes, hints=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop_coalesced(n_co, hints=False)
+        torch.cuda.synchronize()
+        dt_nh = (time.perf_counter() - t0) / n_co
+        model.sync_check()
+        model.coalesce = 0
         model.lanes = 1
-        res["one_clip_per_pass"] = {"value": T / dt1, "unit": "frames/s", "ms_per_step": 1e3 * dt1, "calls": 2 * n1,
-                                    "lanes": nlanes, "serial": {"value": T / dt_serial, "ms_per_step": 1e3 * dt_serial},
-                                    "note": "same clip shape with clips_per_step = 1: the reference's batch "
-                                            "(dataloader/wk_action_genome.py:622-627), a different entry on every call, "
-                                            f"{nlanes} calls in flight on the handle's lanes (forward_async / join); "
-                                            "`serial` = one call at a time on the caller's stream"}
+        res["one_clip_per_pass"] = {"value": T / dt_co, "unit": "frames/s", "ms_per_step": 1e3 * dt_co, "calls": n_co,
+                                    "lanes": nlanes, "coalesce": K,
+                                    "no_hints": {"value": T / dt_nh, "ms_per_step": 1e3 * dt_nh},
+                                    "lanes_only": {"value": T / dt1, "ms_per_step": 1e3 * dt1, "calls": 2 * n1},
+                                    "serial": {"value": T / dt_serial, "ms_per_step": 1e3 * dt_serial},
+                                    "note": "same clip shape, ONE clip per call: the reference's batch "
+                                            "(dataloader/wk_action_genome.py:622-627) and its loop body "
+                                            "(tools/test_STTran.py:75-88) as `pending.append(model.forward_async(entry))` / "
+                                            f"`model.join(pred)`, a different entry on every call; model.coalesce = {K} issues every "
+                                            f"{K} calls as one by-pointer forward on one of {nlanes} lanes; `no_hints` = entries "
+                                            "without host-side frame_counts (one im_idx read-back per group); `lanes_only` = "
+                                            "coalesce off (round 4's figure); `serial` = one call at a time on the caller's stream"}
 
     # ---- the headline's batches, two steps in flight on two lanes of the handle (not `value`: steps overlap) ----
     if one_clip and cps > 1 and world == 1:
@@ -907,8 +949,12 @@ def compact_line(d):
         if k in d:
             out[k] = {"value": _r(d[k]["value"], 1), "ms_per_step": _r(d[k]["ms_per_step"], 4)}
     if "one_clip_per_pass" in d and "serial" in d["one_clip_per_pass"]:
-        out["one_clip_per_pass"]["lanes"] = d["one_clip_per_pass"]["lanes"]
-        out["one_clip_per_pass"]["serial"] = _r(d["one_clip_per_pass"]["serial"]["value"], 1)
+        o = d["one_clip_per_pass"]
+        out["one_clip_per_pass"]["lanes"] = o["lanes"]
+        out["one_clip_per_pass"]["serial"] = _r(o["serial"]["value"], 1)
+        if "coalesce" in o:
+            out["one_clip_per_pass"].update(coalesce=o["coalesce"], no_hints=_r(o["no_hints"]["value"], 1),
+                                            lanes_only=_r(o["lanes_only"]["value"], 1))
     if "pcie_inclusive_overlapped" in d:
         out["pcie_inclusive_overlapped"]["h2d_gb_per_s"] = _r(d["pcie_inclusive_overlapped"]["h2d_gb_per_s"], 1)
     if "allgather_ms" in d:
@@ -935,6 +981,8 @@ def compact_line(d):
             e["one_clip_per_pass"] = _r(blk["one_clip_per_pass"]["value"], 1)
             if "serial" in blk["one_clip_per_pass"]:
                 e["one_clip_serial"] = _r(blk["one_clip_per_pass"]["serial"]["value"], 1)
+            if "lanes_only" in blk["one_clip_per_pass"]:
+                e["one_clip_lanes_only"] = _r(blk["one_clip_per_pass"]["lanes_only"]["value"], 1)
         if "max_abs_diff_vs_fp32_engine" in blk:
             e["max_abs_diff_vs_fp32_engine"] = blk["max_abs_diff_vs_fp32_engine"]
         if "allgather_ms" in blk:

@@ -106,7 +106,16 @@ class STTran:
         self._lanes = 1
         self._lanes_set = 1
         self._next_lane = 0
-        self._inflight = {}             # lane -> tensors of its last un-joined call (see _run)
+        self._inflight = {}             # lane -> (_Group, tensors) of its last un-joined call (see _run)
+        # coalescing (no reference counterpart; the reference's loop is one clip per call, tools/test_STTran.py:75-88 with
+        # dataloader/wk_action_genome.py:622-627): `model.coalesce = K` makes `forward_async(entry)` only QUEUE the entry;
+        # every K queued entries (or `coalesce_max_pairs` queued pairs, or a `join` / `sync_check` / classic `forward`
+        # that needs one of them) are issued as ONE by-pointer batch forward on the next lane -- the unmodified
+        # one-clip-per-call loop then runs at the batch path's rate.  See `forward_async`.
+        self.coalesce = 0
+        self.coalesce_max_pairs = 0     # 0 = no bound; else a group is issued as soon as it holds >= this many pairs
+        self._pending = []              # entries queued by forward_async, not yet issued
+        self._pending_pairs = 0
         self._device = None
         self._handle = None
         self._sd = {}
@@ -202,7 +211,8 @@ class STTran:
             self._handle = None
             self._engine_set = None
             self._lanes_set = 1
-            self._inflight = {}
+            self._drop_inflight()
+            self._pending, self._pending_pairs = [], 0
 
     def __del__(self):
         # Never during interpreter shutdown: module teardown order is arbitrary and the HIP runtime underneath
@@ -254,40 +264,126 @@ class STTran:
             nat.check(self._lib, self._handle, self._lib.sttran_set_lanes(self._handle, self._lanes))
             self._lanes_set = self._lanes          # (sttran_set_lanes synchronised the device: nothing is in flight)
             self._next_lane = 0
-            self._inflight = {}
+            self._drop_inflight()
+
+    @property
+    def pipeline_depth(self):
+        """Entries a caller's loop should keep un-joined so that every lane holds a full group: lanes x max(coalesce, 1)."""
+        return self._lanes * max(int(self.coalesce), 1)
 
     def forward_async(self, entry):
         """`forward(entry)` on the next lane (round robin over `model.lanes`), WITHOUT making the current stream wait for
         it: the call returns as soon as the work is enqueued on the lane's own stream (forked from the current stream, so
         whatever produced `entry` there precedes it).  The output tensors are valid for a consumer on the current stream
         only after `model.join(entry)` (or `sync_check()`, which joins every lane).  The loop of tools/test_STTran.py:81-92
-        in this form keeps `lanes` clips in flight:
+        in this form keeps `pipeline_depth` clips in flight:
 
             pending = collections.deque()
             for entry, gt in loader:
                 pending.append((model.forward_async(entry), gt))
-                if len(pending) == model.lanes:
+                if len(pending) == model.pipeline_depth:
                     pred, g = pending.popleft(); evaluator.evaluate_scene_graph(g, model.join(pred))
 
+        With `model.coalesce = K` (> 1) the call only queues `entry`; the K-th queued entry (or the one that brings the
+        queue to `coalesce_max_pairs` pairs) issues the whole group as ONE forward over per-clip pointer tables
+        (`pack_clips(group, copy=False)`: nothing is copied) on the next lane, and every entry of the group receives its
+        `attention/spatial/contacting_distribution` (+ `distribution`, `pred_labels`, `pred_scores`) as row views of the
+        group's outputs -- the same keys, shapes and values as the one-clip call (bit-identical to the packed forward of the
+        group).  A `join(entry)` of a still-queued entry issues its (partial) group first: a join never waits for entries
+        that have not been submitted.  `sync_check()`, `join()` and a classic `forward` issue what is queued, too.
+
         `check_indices` is not applied per call here (it would synchronise); index errors raise at `sync_check()`.
-        Results are bit-identical to `forward`'s."""
+        Results are bit-identical to `forward`'s (coalesce off) / to the packed forward of the same group (coalesce on)."""
+        if int(self.coalesce) > 1 and not (isinstance(entry, PackedClips) and entry.by_pointer):
+            return self._submit(entry)
+        self._flush()
         self._async = True
         try:
             return self.forward(entry)
         finally:
             self._async = False
 
+    def _submit(self, entry):
+        if self._select:
+            from .object_classifier import sgdet_select
+            entry = sgdet_select(entry)                      # lib/sttran.py:377 -> :185-283 (per clip: data-dependent sizes)
+        P = int(entry["pair_idx"].shape[0])
+        if P == 0:
+            raise nat.SttranError(3, "entry has no pairs")
+        entry["_group"] = None                               # queued: no group yet
+        self._pending.append(entry)
+        self._pending_pairs += P
+        if len(self._pending) >= int(self.coalesce) or 0 < int(self.coalesce_max_pairs) <= self._pending_pairs:
+            self._flush()
+        return entry
+
+    def _flush(self):
+        """Issue the queued entries as one by-pointer forward on the next lane and hand every entry its rows."""
+        if not self._pending:
+            return
+        group, self._pending, self._pending_pairs = self._pending, [], 0
+        lab = "pred_labels" if self._select else "labels"
+        clips = [e if lab == "labels" else dict(e, labels=e[lab]) for e in group]
+        packed = pack_clips(clips, copy=False)
+        packed.selected = self._select                      # (sgdet without wks: every clip went through sgdet_select)
+        self._async = True
+        try:
+            self.forward(packed)
+        except Exception:
+            for e in group:
+                e.pop("_group", None)
+            raise
+        finally:
+            self._async = False
+        p0 = b0 = 0
+        dist = packed.get("distribution") if self.mode != "predcls" and not self._select else None
+        for e, np_, nb in zip(group, packed["_pairs_per_clip"], packed["_boxes_per_clip"]):
+            for k in ("attention_distribution", "spatial_distribution", "contacting_distribution"):
+                e[k] = packed[k][p0:p0 + np_]
+            for k in ("rel_features", "local_output", "global_output"):
+                if "_tap_" + k in packed:
+                    e["_tap_" + k] = packed["_tap_" + k][p0:p0 + np_]
+            if not self._select:
+                e["pred_labels"] = e["labels"]               # lib/sttran.py:91
+            if dist is not None:
+                e["distribution"] = dist[b0:b0 + nb]         # lib/sttran.py:182-184
+                e["pred_scores"] = e["scores"]
+            e["_group"], e["_lane"] = packed["_group"], packed["_lane"]
+            p0 += np_
+            b0 += nb
+
+    def _drop_inflight(self, lane=None):
+        """The tensors kept for a lane's last call are released: its group counts as joined."""
+        for l in (list(self._inflight) if lane is None else [lane]):
+            rec = self._inflight.pop(l, None)
+            if rec is not None:
+                rec[0].joined = True
+
     def join(self, entry=None):
-        """Make the current stream wait for the lane that computed `entry` (None: for every lane); returns `entry`."""
+        """Make the current stream wait for the forward that computed `entry` (None: for every lane); returns `entry`.
+        A still-queued entry (`coalesce`) is issued first.  Joining an entry whose group was already joined (another entry
+        of the same coalesced group, or a lane that has been reused since) is free: it never waits for a LATER forward."""
+        if entry is None or entry.get("_group", 0) is None:
+            self._flush()
         if self._handle is not None:
-            lane = -1 if entry is None else int(entry.get("_lane", -1))
             dev = torch.device("cuda", self._device)
-            nat.check(self._lib, self._handle,
-                      self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-            if lane < 0:
-                self._inflight = {}
+            cur = torch.cuda.current_stream(dev).cuda_stream
+            if entry is None:
+                lanes = [-1] if self._inflight else []
+                streams = {rec[0].stream for rec in self._inflight.values()}
             else:
-                self._inflight.pop(lane, None)
+                g = entry.get("_group")
+                if g is None or g.joined:
+                    return entry
+                lanes, streams = [g.lane], {g.stream}
+            for lane in lanes:
+                nat.check(self._lib, self._handle, self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(cur)))
+                # torch's caching allocator recycles a block on the stream it was ALLOCATED on (the current stream of the
+                # forward_async call): when the join happens under another stream, that stream must wait for the lane too
+                # before the kept tensors are dropped
+                for st in streams - {cur}:
+                    nat.check(self._lib, self._handle, self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(st)))
+            self._drop_inflight(None if entry is None else lanes[0])
         return entry
 
     _async = False
@@ -322,9 +418,10 @@ class STTran:
     def sync_check(self):
         """Wait for the current stream and raise if a kernel met an out-of-range pair_idx / labels entry since the
         last check (what `check_indices=True` does after every call)."""
+        self._flush()
         stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
         rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
-        self._inflight = {}                             # sync_check joined every lane and waited
+        self._drop_inflight()                           # sync_check joined every lane and waited
         if rc == 7:                                     # STTRAN_ERR_INDEX: what torch raises as an IndexError
             msg = self._lib.sttran_last_error(self._handle) or b""
             raise nat.SttranIndexError(rc, msg.decode("utf-8", "replace"))
@@ -338,6 +435,8 @@ class STTran:
         that avoid the read-back of `im_idx`: `frame_counts` (pairs per frame) and, for a batch of
         clips packed by `pack_clips`, `clip_num_frames`."""
         self._ensure_handle()
+        if self._pending and not self._async:
+            self._flush()                                    # queued entries precede a classic forward
         self._sync_lanes()
         lib, h = self._lib, self._handle
         if self._engine_set != self.gemm_engine:
@@ -409,13 +508,13 @@ class STTran:
     def _forward_by_pointer(self, packed):
         """A batch of clips handed over as per-clip pointer tables (`pack_clips(entries, copy=False)`): every clip's
         tensors stay where its producer left them (include/sttran_hip.h, SttranInputs form 2)."""
-        if self._select:
+        if self._select and not packed.selected:
             raise NotImplementedError("sgdet without weak supervision selects boxes per clip: forward the clips one by one "
-                                      "or pack the selected entries")
+                                      "(or through forward_async with `coalesce`, which selects per clip and batches the rest)")
         lib, f32, i64 = self._lib, torch.float32, torch.int64
         clips = packed.clips
         n = len(clips)
-        sg = self.mode != "predcls"
+        sg = self.mode != "predcls" and not self._select
         names = ["features", "pair_idx", "labels", "union_feat", "spatial_masks"] + (["boxes", "distribution"] if sg else [])
         tabs = {k: (C.c_void_p * n)() for k in names}
         nb, npairs = (C.c_int64 * n)(), (C.c_int64 * n)()
@@ -478,11 +577,16 @@ class STTran:
             # there while the lane is still using it.  So the shim keeps a reference to every tensor of the call until the
             # lane has been joined into the current stream (`join`, `sync_check`) -- or until the lane's next call, which
             # joins it first (that call was issued `lanes` calls ago: the wait is normally already satisfied).
-            if self._inflight.get(lane):
+            prev = self._inflight.get(lane)
+            if prev is not None:
                 nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(stream)))
+                if prev[0].stream != stream:                 # (see `join`: the allocating stream must have waited as well)
+                    nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(prev[0].stream)))
+                self._drop_inflight(lane)
             nat.check(lib, h, lib.sttran_forward_lane(h, lane, C.byref(inp), C.byref(out), C.c_void_p(stream)))
-            self._inflight[lane] = (keep, att, spa, con, dist_out, taps)
-            entry["_lane"] = lane
+            group = _Group(lane, stream)
+            self._inflight[lane] = (group, keep, att, spa, con, dist_out, taps)
+            entry["_lane"], entry["_group"] = lane, group
         else:
             nat.check(lib, h, lib.sttran_forward(h, C.byref(inp), C.byref(out), C.c_void_p(stream)))
         del keep                                             # (the launches read device memory that `entry` keeps alive)
@@ -504,6 +608,16 @@ class STTran:
         return entry
 
 
+class _Group:
+    """One forward issued on a lane: which lane, the stream it was forked from (= the stream torch allocated its tensors
+    on), and whether a consumer stream has been ordered behind it since (then its kept tensors are gone and a `join` of any
+    of its entries is free)."""
+    __slots__ = ("lane", "stream", "joined")
+
+    def __init__(self, lane, stream):
+        self.lane, self.stream, self.joined = lane, stream, False
+
+
 class PackedClips(dict):
     """What `pack_clips` returns: a batch of clips as ONE entry.  With `copy=False` (`by_pointer`) the big tensors are
     NOT concatenated -- `clips` keeps the original per-clip dicts and the model hands their pointers to the library --;
@@ -517,6 +631,7 @@ class PackedClips(dict):
         super().__init__(*a, **kw)
         self.clips = None
         self.by_pointer = False
+        self.selected = False
 
     def __missing__(self, key):
         if self.by_pointer and key in ("pred_labels", "pred_scores"):          # lib/sttran.py:91,184: aliases of the inputs
@@ -548,10 +663,23 @@ def pack_clips(entries, copy=True):
     entries = list(entries)
     cat = PackedClips()
     counts, clips = [], []
-    for e in entries:
+    # entries without the `frame_counts` hint (the reference's entries carry none): ONE read-back of their `im_idx`
+    # vectors (concatenated on the device: a few hundred bytes per clip), not one synchronisation per clip
+    need = [i for i, e in enumerate(entries) if e.get("frame_counts") is None]
+    host_im = {}
+    if need:
+        ims = [entries[i]["im_idx"] for i in need]
+        if len(need) > 1 and all(isinstance(t, torch.Tensor) and t.is_cuda for t in ims):
+            flat = torch.cat([t.detach().reshape(-1).to(torch.float64) for t in ims]).cpu().numpy().astype(np.int64)
+            cuts = np.cumsum([0] + [int(t.numel()) for t in ims])
+            host_im = {i: flat[cuts[j]:cuts[j + 1]] for j, i in enumerate(need)}
+        else:
+            host_im = {i: (t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)).astype(np.int64)
+                       for i, t in zip(need, ims)}
+    for i, e in enumerate(entries):
         fc = _host_i32(e.get("frame_counts"))
         if fc is None:
-            fr = e["im_idx"].detach().cpu().numpy().astype(np.int64)
+            fr = host_im[i]
             fc = np.bincount(fr, minlength=int(e.get("num_frames", (fr[-1] + 1) if len(fr) else 0))).astype(np.int32)
         counts.append(fc)
         clips.append(len(fc))
@@ -559,7 +687,7 @@ def pack_clips(entries, copy=True):
     cat["clip_num_frames"] = np.asarray(clips, dtype=np.int32)
     cat["num_frames"] = int(sum(clips))
     cat["_pairs_per_clip"] = [int(e["pair_idx"].shape[0]) for e in entries]
-    cat["_boxes_per_clip"] = [int(e["labels"].shape[0]) for e in entries]
+    cat["_boxes_per_clip"] = [int(e["labels" if "labels" in e else "features"].shape[0]) for e in entries]
     if not copy:
         cat.clips, cat.by_pointer = entries, True
         return cat

@@ -1,0 +1,215 @@
+"""Coalescing `forward_async` (`model.coalesce = K`): the reference's unmodified one-clip-per-call loop
+(tools/test_STTran.py:75-88, batch = `batch[0]` of dataloader/wk_action_genome.py:622-627) runs as by-pointer micro-batches
+on the handle's lanes.  Every entry must receive exactly the rows the packed forward of its group computes (bit for bit),
+which equal the one-clip call's to fp32 rounding (the batch changes the GEMM tiling, never the math); joins come in any
+order, a join of a queued entry issues its partial group, and nothing ever waits for entries that were not submitted."""
+import collections
+import random
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from nl_vsgg_amd.lib import synthetic as syn  # noqa: E402
+
+OUT_KEYS = ("attention_distribution", "spatial_distribution", "contacting_distribution")
+CLASSES = ["__background__"] + [f"c{i}" for i in range(36)]
+SHAPES = [[3, 1, 4, 2, 2], [11] * 16, [2, 0, 3, 0, 0, 2], [5], [1, 1, 1], [7, 9, 8, 2, 6, 6, 6, 1, 4], [35] * 6, [4, 4], [0, 2, 3]]
+
+
+def _model(mode, sd, model="sttran", **kw):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if model == "dsgdetr":
+        from nl_vsgg_amd.lib.dsg_detr import STTran
+        m = STTran(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
+    else:
+        from nl_vsgg_amd.lib.sttran import STTran
+        m = STTran(mode=mode, attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES,
+                   enc_layer_num=1, dec_layer_num=3, transformer_mode="wk", feat_dim=2048, **({"is_wks": True} | kw)).to("cuda:0")
+    m.eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    m.check_indices = False
+    return m
+
+
+def _cuda_entry(e, hints=True):
+    """`hints=False`: the reference's entry -- no host-side `frame_counts` / `num_frames` (the shim reads `im_idx` back,
+    once per GROUP when coalescing)"""
+    out = {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) and k != "frame_counts" else v) for k, v in e.items()}
+    if not hints:
+        out.pop("frame_counts", None); out.pop("num_frames", None)
+    return out
+
+
+def _entries(mode, n, seed=700, im_dtype=None):
+    kw = {"im_idx_dtype": im_dtype} if im_dtype is not None else {}
+    return [syn.make_entry(seed + i, SHAPES[i % len(SHAPES)], mode=mode, **kw) for i in range(n)]
+
+
+def _keys(mode):
+    return OUT_KEYS + (("distribution",) if mode == "sgdet" else ())
+
+
+def _serial(m, entries, mode):
+    want = []
+    for e in entries:
+        p = m(_cuda_entry(e))
+        want.append({k: p[k].clone() for k in _keys(mode)})
+    torch.cuda.synchronize()
+    return want
+
+
+def _packed(m, entries, mode, K):
+    """what the coalesced loop must reproduce bit for bit: the by-pointer forward of every group of K"""
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    want = []
+    for g in range(0, len(entries), K):
+        group = [_cuda_entry(e) for e in entries[g:g + K]]
+        p = m(pack_clips(group, copy=False))
+        want += [{k: v.clone() for k, v in d.items()} for d in unpack_predictions(p)]
+    torch.cuda.synchronize()
+    return want
+
+
+@pytest.mark.parametrize("mode,model", [("predcls", "sttran"), ("sgdet", "sttran"), ("sgdet", "dsgdetr")])
+@pytest.mark.parametrize("K,lanes", [(4, 2), (3, 3), (16, 1)])
+def test_coalesced_loop_equals_packed_and_serial(mode, model, K, lanes):
+    sd = syn.make_dsg_detr_state_dict(7) if model == "dsgdetr" else syn.make_sttran_state_dict(7)
+    m = _model(mode, sd, model=model)
+    n = 2 * len(SHAPES) + 1                                # not a multiple of K: a partial final group
+    entries = _entries(mode, n, im_dtype=np.int64 if model == "dsgdetr" else None)
+    serial = _serial(m, entries, mode)
+    packed = _packed(m, entries, mode, K)
+    m.lanes, m.coalesce = lanes, K
+    assert m.pipeline_depth == lanes * K
+    pending, got = collections.deque(), []
+    for i, e in enumerate(entries):                        # the reference's loop body, literally
+        pending.append(m.forward_async(_cuda_entry(e, hints=(i % 2 == 0))))
+        if len(pending) == m.pipeline_depth:
+            p = m.join(pending.popleft())
+            got.append({k: p[k].clone() for k in _keys(mode)})
+    while pending:
+        p = m.join(pending.popleft())
+        got.append({k: p[k].clone() for k in _keys(mode)})
+    m.sync_check()
+    assert len(got) == n
+    for i, (g, w, s) in enumerate(zip(got, packed, serial)):
+        for k in _keys(mode):
+            assert g[k].shape == s[k].shape, (i, k)
+            if k in w:
+                assert torch.equal(g[k], w[k]), (i, k)
+            assert float((g[k] - s[k]).abs().max()) <= 2e-5, (i, k)
+
+
+def test_joins_in_arbitrary_order_and_partial_groups():
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("predcls", sd)
+    entries = _entries("predcls", 23, seed=900)
+    K = 5
+    packed = _packed(m, entries, "predcls", K)
+    m.lanes, m.coalesce = 3, K
+    preds = [m.forward_async(_cuda_entry(e)) for e in entries]
+    # 23 = 4 full groups (issued) + 3 queued; entry 22 is still queued and has no outputs yet
+    assert preds[22]["_group"] is None and "attention_distribution" not in preds[22]
+    assert preds[0]["_group"] is preds[4]["_group"] and preds[4]["_group"] is not preds[5]["_group"]
+    assert [preds[5 * g]["_lane"] for g in range(4)] == [0, 1, 2, 0]
+    order = list(range(23))
+    random.Random(5).shuffle(order)
+    outs = {}
+    for i in order:
+        p = m.join(preds[i])                               # the first join of a queued entry issues the partial group
+        outs[i] = {k: p[k].clone() for k in OUT_KEYS}
+    assert preds[22]["_group"] is preds[20]["_group"] and preds[22]["_group"].joined
+    torch.cuda.synchronize()
+    for i in range(23):
+        assert all(torch.equal(outs[i][k], packed[i][k]) for k in OUT_KEYS), i
+    # row views of ONE allocation per group (no copy on the way out), written with the reference's keys
+    a, b = preds[0]["attention_distribution"], preds[1]["attention_distribution"]
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    assert preds[3]["pred_labels"] is preds[3]["labels"]
+
+
+def test_max_pairs_bound_and_classic_forward_flushes():
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("predcls", sd)
+    big, small = syn.make_entry(31, [11] * 16), syn.make_entry(32, [3, 1, 4, 2, 2])
+    want_big = {k: v.clone() for k, v in m(_cuda_entry(big)).items() if k in OUT_KEYS}
+    torch.cuda.synchronize()
+    m.lanes, m.coalesce, m.coalesce_max_pairs = 2, 64, 300
+    a = m.forward_async(_cuda_entry(small))                # 12 pairs: queued
+    b = m.forward_async(_cuda_entry(big))                  # 188 pairs: queued
+    assert a["_group"] is None and b["_group"] is None
+    c = m.forward_async(_cuda_entry(big))                  # 364 >= 300: the group of three is issued
+    assert a["_group"] is not None and a["_group"] is c["_group"]
+    d = m.forward_async(_cuda_entry(small))                # queued again
+    assert d["_group"] is None
+    p = m(_cuda_entry(big))                                # a classic forward issues what is queued first, then runs
+    assert d["_group"] is not None and d["_group"] is not a["_group"]
+    m.sync_check()
+    assert all(torch.equal(p[k], want_big[k]) for k in OUT_KEYS)
+    assert float((c["attention_distribution"] - want_big["attention_distribution"]).abs().max()) <= 2e-5
+    # an entry without pairs is refused at submission (the one-clip call refuses it too), the queue is untouched
+    empty = _cuda_entry(small)
+    empty["pair_idx"] = empty["pair_idx"][:0]
+    with pytest.raises(Exception):
+        m.forward_async(empty)
+    m.coalesce = 0                                         # off again: forward_async is the plain lane call
+    e = m.join(m.forward_async(_cuda_entry(big)))
+    torch.cuda.synchronize()
+    assert all(torch.equal(e[k], want_big[k]) for k in OUT_KEYS)
+
+
+def test_join_under_another_stream_than_the_forward():
+    """the kept tensors are released only after the stream they were allocated on has waited for the lane, even
+    when `join` is called under a different current stream"""
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("predcls", sd)
+    e = syn.make_entry(41, [11] * 16)
+    want = {k: v.clone() for k, v in m(_cuda_entry(e)).items() if k in OUT_KEYS}
+    torch.cuda.synchronize()
+    m.lanes, m.coalesce = 2, 2
+    side = torch.cuda.Stream()
+    for rep in range(8):
+        ps = [m.forward_async(_cuda_entry(e)) for _ in range(4)]
+        outs = []
+        with torch.cuda.stream(side):
+            for p in ps:
+                m.join(p)
+                outs.append({k: p[k].clone() for k in OUT_KEYS})
+                for k in OUT_KEYS:
+                    p[k].record_stream(side)               # the consumer's own duty for a tensor it reads on another stream
+        del ps, p
+        junk = [torch.full((176, 17), float(rep), device="cuda") for _ in range(64)]     # would recycle freed blocks at once
+        side.synchronize()
+        for o in outs:
+            assert all(float((o[k] - want[k]).abs().max()) <= 2e-5 for k in OUT_KEYS), rep
+        del junk
+    m.sync_check()
+
+
+def test_sgdet_without_wks_coalesced():
+    """`STTran(mode='sgdet', is_wks=False)`: boxes / pairs are selected per clip at submission (data-dependent sizes), the
+    relation transformer then runs once per group"""
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("sgdet", sd, is_wks=False)
+    shapes = [[9, 12, 7], [5, 6], [8, 3, 4, 6]]
+    mk = lambda i: syn.make_detector_entry(450 + i, shapes[i % 3], feat_dim=2048, fmap_channels=2048, fmap_hw=(12, 16),
+                                           image_wh=(256.0, 192.0))
+    to_cuda = lambda e: {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in e.items()}
+    n = 7
+    want = []
+    for i in range(n):
+        p = m(to_cuda(mk(i)))
+        want.append({k: p[k].clone() for k in OUT_KEYS + ("pair_idx", "pred_labels")})
+    torch.cuda.synchronize()
+    m.lanes, m.coalesce = 2, 3
+    preds = [m.forward_async(to_cuda(mk(i))) for i in range(n)]
+    m.join()
+    m.sync_check()
+    for p, w in zip(preds, want):
+        assert torch.equal(p["pair_idx"], w["pair_idx"]) and torch.equal(p["pred_labels"], w["pred_labels"])
+        for k in OUT_KEYS:
+            assert p[k].shape == w[k].shape and float((p[k] - w[k]).abs().max()) <= 2e-5, k
