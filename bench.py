@@ -287,11 +287,12 @@ def strong_scaling(env, model, name, clip_specs, pack, cost_of):
         pack_gt.append(g)
     my_rows = [sum(int(mine[i][0]["pair_idx"].shape[0]) for i in pk) for pk in packs[rank]]
     all_rows = [my_rows]
-    if world > 1:
+    coll = env.dist is not None            # N > 1, or the 1-rank RCCL self-test: the same collectives on a group of one
+    if coll:
         all_rows = [None] * world
         env.dist.all_gather_object(all_rows, my_rows)
     rows_cap = max(max((max(r, default=1) for r in all_rows), default=1), 1)
-    gatherer = PredictionGatherer(rows_cap, pack, cols=26, device=device, depth=2) if world > 1 else None
+    gatherer = PredictionGatherer(rows_cap, pack, cols=26, device=device, depth=2) if coll else None
     model.reserve(max(my_rows, default=1), max((sum(int(mine[i][0]["labels"].shape[0]) for i in pk) for pk in packs[rank]),
                                                default=1))
     stat = {"busy_s": 0.0, "eval_s": 0.0, "gather_mismatch": 0}
@@ -376,7 +377,7 @@ def strong_scaling(env, model, name, clip_specs, pack, cost_of):
     per_rank = [{"rank": rank, "clips": len(lists[rank]), "frames": sum(clip_specs[i][0] for i in lists[rank]),
                  "passes": len(packs[rank]), "busy_s": stat["busy_s"], "eval_s": stat["eval_s"],
                  "gather_mismatch": stat["gather_mismatch"]}]
-    if world > 1:
+    if coll:
         allr = [None] * world
         env.dist.all_gather_object(allr, per_rank[0])
         per_rank = allr
@@ -389,7 +390,7 @@ def strong_scaling(env, model, name, clip_specs, pack, cost_of):
            "lpt_imbalance": max(loads) / (sum(loads) / world) if sum(loads) else 1.0,
            "busy_imbalance": max(busy) / (sum(busy) / world) if sum(busy) else 1.0,
            "busy_max_s": max(busy), "eval_max_s": max(p_["eval_s"] for p_ in per_rank), "eval_s_rank0": per_rank[0]["eval_s"],
-           "gather_verified": world > 1,
+           "gather_verified": gatherer is not None, "host_threads_per_rank": env.host_threads,
            "recall_with_constraint": {str(k): round(float(v), 4) for k, v in table["recall"].items()},
            "config": {"workload": name, "sharding": f"assign_clips (LPT on pairs x frames) over {world} rank(s); every rank scores its own "
                                                     f"clips on its GPU; one all-gather of [pairs, 26] rows per round + one all-reduce of "
@@ -411,16 +412,36 @@ class Env:
         # one process per GPU; BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only so the N>1 code path can be
         # smoke-tested on a single-GPU box (all ranks on device 0, gloo instead of RCCL): tests/test_bench_gpu.py
         self.local = int(os.environ.get("BENCH_FORCE_DEVICE", local))
-        if self.local >= torch.cuda.device_count():
-            print(f"bench.py: rank {self.rank}: device ordinal {self.local} does not exist ({torch.cuda.device_count()} GPU(s) "
-                  f"visible)", file=sys.stderr)
+        ndev = torch.cuda.device_count()
+        forced = "BENCH_FORCE_DEVICE" in os.environ
+        missing = [r for r in range(self.world) if r >= ndev] if not forced else ([self.rank] if self.local >= ndev else [])
+        if missing:
+            # A mis-provisioned run (fewer GPUs than ranks; one node: LOCAL_RANK = ordinal) must still leave a parseable
+            # record: EVERY rank leaves before the rendezvous (the ranks whose ordinal exists would wait for the others in
+            # init_process_group) and rank 0 -- whose ordinal 0 exists whenever any GPU does -- prints a compact line
+            # carrying "error"; exit code 2.
+            msg = f"rank {missing[0]}: no device {missing[0]} ({ndev} GPU(s) visible, {self.world} rank(s))"
+            print(f"bench.py: rank {self.rank}: {msg}", file=sys.stderr)
+            if self.rank == 0:
+                print(error_line(args, self.world, msg), flush=True)
             raise SystemExit(2)
         torch.cuda.set_device(self.local)
         self.device = torch.device("cuda", self.local)
+        # host threads of this rank: the evaluator's tally, torch's CPU ops and numpy run in this process next to 7 others
+        # on an 8-GPU node -- cap torch's intra-op pool so N ranks do not each start one thread per host core
+        cores = os.cpu_count() or 1
+        self.host_threads = max(1, cores // (2 * self.world)) if self.world > 1 else None
+        if self.host_threads:
+            torch.set_num_threads(self.host_threads)
         self.dist = None
-        if self.world > 1:
+        if self.world > 1 or getattr(args, "rccl_selftest", False):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1 and "MASTER_PORT" not in os.environ:      # --rccl-selftest without a launcher
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND", "nccl"))    # nccl == RCCL on ROCm
             self.dist = dist
 
@@ -430,21 +451,21 @@ class Env:
         mine = {"rank": self.rank, "device": self.local, "pci_bus_id": pci_bus_id(self.local), "name": pr.name,
                 "uuid": str(getattr(pr, "uuid", "")) or None, "pid": os.getpid(),
                 "backend": self.dist.get_backend() if self.dist else None}
-        if self.world == 1:
+        if self.dist is None:
             return [mine]
         out = [None] * self.world
         self.dist.all_gather_object(out, mine)
         return out
 
     def max_over_ranks(self, seconds):
-        if self.world == 1:
+        if self.dist is None:
             return seconds
         t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def barrier(self, gatherer=None):
-        if self.world > 1:
+        if self.dist is not None:
             if gatherer is not None:
                 gatherer.wait_all()
             if self.dist.get_backend() == "nccl":
@@ -897,6 +918,46 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
 COMPACT_LIMIT = 4096
 
 
+def error_line(args, world, msg):
+    """A compact line for a run that could not start (no device for a rank): every contract key, value 0, and `error`."""
+    return json.dumps({"metric": "frames/sec (PredCls inference)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                       "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "not run"},
+                       "roofline": None, "cpu_baseline": None, "error": msg[:200]})
+
+
+def rccl_selftest(env, model):
+    """`bench.py --gpus 1 --rccl-selftest` (run by the default line as a FRESH child process with a time limit, so a
+    communicator that does not come up cannot cost the line): a ONE-rank `nccl` (= RCCL) process group in this process and,
+    over it, exactly the code the N > 1 legs run -- `strong_scaling` on a small 64x36 set: `PredictionGatherer.submit` under
+    the next forward in flight on the handle's lanes, `gathered()` verified against what the rank computed,
+    `all_reduce_recall`, `Env.barrier` / `max_over_ranks` -- plus the back-to-back all-gather timing of `run_workload`.
+    That loads librccl, creates a communicator and runs its all-gather / all-reduce kernels on the device with the stream
+    ordering of lib/distributed.py; what it cannot exercise is the xGMI transport between two GPUs (RCCL refuses two ranks
+    on one device: the 2-rank smoke tests stay on gloo)."""
+    t0 = time.perf_counter()
+    out = {"backend": env.dist.get_backend(), "world": env.world}
+    ss = strong_scaling(env, model, "rccl self-test: 8 clips of 64x36, 4 per forward", [(64, [35] * 64)] * 8, 4,
+                        lambda sp: float(sp[0]) * float(np.sum(sp[1])))
+    out.update(gather_verified=ss["gather_verified"], frames_per_s=ss["value"], rounds=ss["rounds"],
+               recall_at_20=ss["recall_with_constraint"].get("20"))
+    P = 4 * 64 * 35
+    g2 = PredictionGatherer(P, 4, cols=26, device=env.device, depth=1)
+    rows = torch.randn(P, 26, device=env.device)
+    for _ in range(3):
+        g2.submit(rows, [0, 1, 2, 3], [64 * 35] * 4); g2.wait_all()
+    env.barrier()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        g2.submit(rows, [0, 1, 2, 3], [64 * 35] * 4); g2.wait_all()
+    torch.cuda.synchronize()
+    out["allgather_ms"] = 1e3 * (time.perf_counter() - t1) / 20
+    got = g2.result(g2.submit(rows, [0, 1, 2, 3], [64 * 35] * 4))
+    out["ok"] = bool(ss["gather_verified"] and sorted(got) == [0, 1, 2, 3] and torch.equal(got[2], rows[2 * 2240:3 * 2240]))
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def _r(x, nd=4):
     """floats rounded for the compact line (the detail file keeps full precision)"""
     if isinstance(x, float):
@@ -959,6 +1020,11 @@ def compact_line(d):
         out["pcie_inclusive_overlapped"]["h2d_gb_per_s"] = _r(d["pcie_inclusive_overlapped"]["h2d_gb_per_s"], 1)
     if "allgather_ms" in d:
         out["allgather_ms"], out["allgather_bytes_per_rank"] = _r(d["allgather_ms"]), d["allgather_bytes_per_rank"]
+    if "rccl_selftest" in d:
+        st = d["rccl_selftest"]
+        out["rccl_selftest"] = {k: _r(st[k]) for k in ("ok", "backend", "allgather_ms", "gather_verified", "seconds") if k in st}
+        if "error" in st:
+            out["rccl_selftest"]["error"] = str(st["error"])[:120]
     if "batch_sweep" in d:
         out["batch_sweep"] = {str(b["clips_per_step"]): _r(b["value"], 1) for b in d["batch_sweep"]}
     if "reference_arithmetic" in d:
@@ -1045,6 +1111,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the second workload (64x36) and the one-clip-per-pass leg of a default run")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1 only: create a one-rank RCCL process group and run the gather / all-reduce / barrier code of the "
+                         "N > 1 legs over it; prints {\"rccl_selftest\": {...}} and exits (the default run starts this as a child)")
+    ap.add_argument("--no-rccl-selftest", action="store_true")
     ap.add_argument("--profile-only-batch", action="store_true",
                     help="warm-up + timed steps of the selected workload only (for rocprofv3 runs: per-kernel averages "
                          "of the trace are then per-step averages)")
@@ -1080,6 +1150,20 @@ def main():
     model.strict_inputs = True       # a hidden per-step copy of the inputs would be timed as compute
     model.gemm_engine = args.gemm_engine
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+
+    if args.rccl_selftest:
+        if world != 1:
+            raise SystemExit("--rccl-selftest is the N = 1 leg (N > 1 runs the same code over the real group)")
+        try:
+            st = rccl_selftest(env, model)
+        except Exception as e:
+            st = {"ok": False, "error": repr(e)[:300]}
+        print(json.dumps({"rccl_selftest": st}), flush=True)
+        try:
+            env.dist.destroy_process_group()
+        except Exception:
+            pass
+        raise SystemExit(0 if st.get("ok") else 1)
 
     extras = not args.no_extra_workloads
     pcie = "full" if args.pcie else ("overlapped" if extras and world == 1 and not args.no_pcie and not args.graph else False)
@@ -1214,6 +1298,20 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                           # an extra block must never cost the line
             result["workloads"]["dsgdetr_16x12"] = {"error": repr(e)}
+    if (extras and world == 1 and args.model == "sttran" and args.workload == "16x12" and not args.no_rccl_selftest
+            and not args.no_strong and args.gemm_engine == "fp32"):
+        # RCCL has no other way to run on a 1-GPU box: a fresh child (never an exec) with a time limit; its verdict rides
+        # in the line.  This process's model is gone and its cached blocks were released above.
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-selftest", "--gpus", "1"],
+                                capture_output=True, text=True, timeout=240,
+                                env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+            last = [l for l in cp.stdout.strip().splitlines() if l.startswith("{")]
+            result["rccl_selftest"] = json.loads(last[-1])["rccl_selftest"] if last else {"ok": False, "error": cp.stderr[-300:]}
+        except subprocess.TimeoutExpired:
+            result["rccl_selftest"] = {"ok": False, "error": "no verdict within 240 s"}
+        except Exception as e:
+            result["rccl_selftest"] = {"ok": False, "error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "sttran":
         result["cpu_baseline"] = cpu_baseline(T, N, sd)
         if extras and "workloads" in result and other in result["workloads"] and "error" not in result["workloads"][other]:

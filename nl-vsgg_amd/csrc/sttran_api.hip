@@ -618,7 +618,7 @@ int lane_create(SttranHandle* h, Lane** out) {
       hipStreamCreateWithFlags(&L->own, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&L->done_ev, hipEventDisableTiming) != hipSuccess) {
-    delete L;
+    lane_destroy(L);                                     // releases whatever was created before the failing call
     return fail(h, STTRAN_ERR_HIP, "lane: stream / event / flag allocation failed");
   }
   if (hipDeviceSynchronize() != hipSuccess) {            // the memset above ran in the NULL stream; L->own does not wait for it
@@ -881,6 +881,9 @@ int sttran_set_lanes(SttranHandle* h, int32_t lanes) {
   HIPCK(hipSetDevice(h->cfg.device));
   HIPCK(hipDeviceSynchronize());                         // nothing of this handle is in flight while lanes come and go
   while ((int)h->lanes.size() > lanes) { lane_destroy(h->lanes.back()); h->lanes.pop_back(); }
+  // the device is idle and every recorded event has completed: a profile_read after this must not synchronise a stream
+  // that may just have been destroyed with its lane (the last forward's stream may have been a lane's own)
+  h->prof_stream = nullptr;
   while ((int)h->lanes.size() < lanes) {
     Lane* L = nullptr;
     int rc = lane_create(h, &L);
@@ -929,7 +932,7 @@ int sttran_profile_reset(SttranHandle* h) {
 
 int sttran_profile_read(SttranHandle* h, SttranProfile* out) {
   if (!h || !out || out->struct_size != sizeof(SttranProfile)) return STTRAN_ERR_INVALID;
-  HIPCK(hipStreamSynchronize(h->prof_stream));
+  if (h->prof_stream) HIPCK(hipStreamSynchronize(h->prof_stream));
   for (Lane* L : h->lanes)
     if (L->used) HIPCK(hipEventSynchronize(L->done_ev));
   for (auto& e : h->prof_ev) {

@@ -105,6 +105,11 @@ class PredictionGatherer:
             for w in self._works[k]:
                 w.wait()
             self._works[k] = None
+            # a rank whose submit did not fit sends an OVERFLOW record and no rows: counted HERE, once per gather, on the
+            # first wait for its buffer set (ring reuse, `wait_all`, `gathered`, `result`) and where it lives (no read-back)
+            # -- so a loop that only submits (bench.py's timed pass) still learns of it through `raise_if_overflowed()`
+            meta = self._meta_all[k].view(self.world, self.clips_cap, 2)
+            self._overflow_seen += (meta[:, 0, 0] == self.OVERFLOW).sum()
 
     def submit(self, local_rows, clip_ids, clip_pairs):
         """Issue the gather of this rank's rows (`[sum(clip_pairs), cols]`); returns a ticket for `result`."""
@@ -139,14 +144,14 @@ class PredictionGatherer:
         k = ticket % self.depth
         self._wait(k)
         meta = self._meta_all[k].view(self.world, self.clips_cap, 2)
-        # a rank whose submit did not fit sends an OVERFLOW record and no rows: count it where it lives (no read-back
-        # here); `raise_if_overflowed()` -- one synchronisation, whenever the consumer likes -- turns it into the error
-        # `result()` raises, so a consumer of the raw buffers cannot score stale rows without ever hearing of it
-        self._overflow_seen += (meta[:, 0, 0] == self.OVERFLOW).sum()
+        # (OVERFLOW records were counted by `_wait`, once per gather: `raise_if_overflowed()` -- one synchronisation,
+        # whenever the consumer likes -- turns them into the error `result()` raises, so a consumer of the raw buffers
+        # cannot score stale rows without ever hearing of it, however often it asks for the same ticket)
         return self._gathered[k].view(self.world, self.rows_cap, self.cols), meta
 
     def raise_if_overflowed(self):
-        """Synchronises: raises if any gather handed out by `gathered()` carried an OVERFLOW record."""
+        """Synchronises: raises if any gather waited for so far (`wait_all` first, to cover the ones in flight) carried
+        an OVERFLOW record."""
         n = int(self._overflow_seen.item())
         if n:
             self._overflow_seen.zero_()
@@ -205,8 +210,10 @@ def all_reduce_recall(evaluator, group=None, device=None):
     strong-scaling run on rank 0's evaluator; the all-gather of the rows (`PredictionGatherer`) remains the way to bring
     the predictions themselves to every rank.  No reference counterpart (single process, `tools/test_STTran.py:62-92`)."""
     vec = torch.from_numpy(evaluator.partial_sums())
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
+        if device is None and dist.get_backend(group) == "nccl":      # RCCL reduces device tensors only
+            device = torch.device("cuda", torch.cuda.current_device())
         if device is not None:
             vec = vec.to(device)
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)      # (a 1-rank group: the identity, still the collective)
     return evaluator.summary_from_partial_sums(vec.cpu().numpy())

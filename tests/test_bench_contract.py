@@ -175,3 +175,31 @@ def test_newest_driver_bench_line_has_the_contract_fields():
     # only, so that record has no dominant row; since round 5 the row is flat `dominant_*` scalars
     # and every later record must carry it
     _check_compact(d, dominant=os.path.basename(files[-1]) > "BENCH_r04.json")
+
+
+def test_missing_device_leaves_a_parseable_error_line():
+    """a rank whose device ordinal does not exist must not leave the driver without a record -- every
+    rank exits 2 before the rendezvous and rank 0 prints a compact line with every contract key and `error`.  This
+    container has no GPU, so `--gpus 2` under a launcher's environment is exactly that case."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    env.pop("BENCH_FORCE_DEVICE", None)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible: nothing is missing")
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                        env=env, capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 2, cp.stderr[-500:]
+    lines = [l for l in cp.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["value"] == 0.0 and "no device" in d["error"]
+    # the other rank says so on stderr and prints nothing on stdout
+    env["RANK"] = env["LOCAL_RANK"] = "1"
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                        timeout=300)
+    assert cp.returncode == 2 and cp.stdout.strip() == "" and "no device" in cp.stderr

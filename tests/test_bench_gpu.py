@@ -117,7 +117,11 @@ def test_bench_self_launch_propagates_a_failing_rank():
     n = torch.cuda.device_count() + 1
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n)] + SMALL, cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=300)
-    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # ... and rank 0 leaves ONE parseable line that says why (round 5: a mis-provisioned SCALE run must leave a record)
+    assert r.returncode != 0 and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["value"] == 0.0 and f"no device {n - 1}" in d["error"]
 
 
 def test_bench_two_ranks_gloo_on_one_gpu():
@@ -150,8 +154,16 @@ def test_bench_default_line_shape():
     for name in ("64x36", "dsgdetr_16x12", "ag_split_shaped"):
         assert c["workloads"][name]["value"] > 0, name
     assert c["workloads"]["64x36"]["one_clip_per_pass"] > 0 and c["workloads"]["64x36"]["roofline_frac"] > 0
-    dom = c["roofline"]["dominant"]
-    assert "gemm16_kernel" in dom["name"] and 0 < dom["frac"] < 1 and dom["launches_per_step"] >= 1
+    rf = c["roofline"]
+    assert "gemm16_kernel" in rf["dominant_kernel"] and 0 < rf["dominant_frac"] < 1 and rf["dominant_launches_per_step"] >= 1
+    assert not any(isinstance(v, (dict, list)) for v in rf.values())          # flat: what the driver's record keeps
+    assert rf["ms_gemm"] > rf["ms_union_conv"] > rf["ms_mask_conv"] > 0 and rf["ms_attention"] > 0 and rf["ms_layernorm"] > 0
+    # the reference's one-clip loop: coalesced on the lanes (value), lanes only, serial -- in that order
+    o = c["one_clip_per_pass"]
+    assert o["coalesce"] == 16 and o["value"] > o["lanes_only"] > o["serial"] > 0 and o["no_hints"] > o["lanes_only"]
+    # RCCL really ran in this run (a one-rank group in a child process): gather verified, all-gather timed
+    st = c["rccl_selftest"]
+    assert st["ok"] is True and st["backend"] == "nccl" and st["gather_verified"] is True and st["allgather_ms"] > 0, st
     # ---- detail ----
     assert len(d["repeats"]) == 3 and sorted(d["repeats"])[1] == d["value"]
     assert d["roofline"]["traffic_measured_in_run"] is False
@@ -179,3 +191,22 @@ def test_bench_default_line_shape():
     p, _ = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
     assert "roofline" not in p and "workloads" not in p and "one_clip_per_pass" not in p and "cpu_baseline" not in p
     assert "pcie_inclusive_overlapped" not in p
+
+
+def test_rccl_selftest_one_rank_group():
+    """`bench.py --gpus 1 --rccl-selftest`: a ONE-rank RCCL process group, and over it the gather / all-reduce / barrier code
+    of the N > 1 legs (PredictionGatherer under the next forward, gathered rows verified, all_reduce_recall) -- the only way
+    RCCL itself runs on a 1-GPU box (two RCCL ranks on one device are refused)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "BENCH_DIST_BACKEND", "BENCH_FORCE_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--rccl-selftest"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1000:], r.stderr[-2000:])
+    st = json.loads(lines[0])["rccl_selftest"]
+    assert st["ok"] is True and st["backend"] == "nccl" and st["world"] == 1
+    assert st["gather_verified"] is True and st["allgather_ms"] > 0 and st["frames_per_s"] > 0 and st["rounds"] == 2

@@ -342,5 +342,20 @@ def test_gathered_counts_overflow_records():
         with pytest.raises(ValueError):
             g.raise_if_overflowed()
         g.raise_if_overflowed()                                             # reported once
+        # asking twice for the same ticket counts its OVERFLOW record once ...
+        t = g.submit(torch.zeros(5, 26), [0], [5])
+        g.gathered(t); g.gathered(t)
+        assert int(g._overflow_seen) == 1
+        with pytest.raises(ValueError):
+            g.raise_if_overflowed()
+        # ... and a loop that only SUBMITS (bench.py's timed pass never calls gathered() / result()) still hears of it:
+        # the record is counted on the first wait for the buffer set -- ring reuse or wait_all
+        for _ in range(3):
+            g.submit(torch.zeros(5, 26), [0], [5])
+        g.wait_all()
+        assert int(g._overflow_seen) == 3
+        with pytest.raises(ValueError):
+            g.raise_if_overflowed()
+        # all_reduce_recall on a 1-rank group runs the collective (identity) and returns the evaluator's own summary
     finally:
         dist.destroy_process_group()
