@@ -15,6 +15,7 @@
 //     is a compile-time immediate -- no address arithmetic and no bounds tests in the loop.
 // Compute-bound on the MFMA pipe (K is only 98): 364 MFMAs per wave per pair.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -26,7 +27,10 @@ constexpr int kMcPlane = kMcW * kMcW;        // 1089 floats per padded input cha
 constexpr int kMcMask = 2 * kMcPlane;        // one pair
 constexpr int kMcGroups = 13;                // 52 taps (49 real) in groups of 4
 constexpr int kMcPoolCh = 8;                 // channels pooled per round and wave
-constexpr int kMcLdsFloats = 2 * kMcMask + 4 * kMcPoolCh * 196 + 3 * 128;
+constexpr int kMcPoolW = 15;                 // a pooled channel's 14 x 14 conv map with a -inf row above and column left of it
+constexpr int kMcPoolPlane = kMcPoolW * kMcPoolW;   // 225 floats (odd: channels start on different LDS banks)
+constexpr int kMcLdsFloats = 2 * kMcMask + 4 * kMcPoolCh * kMcPoolPlane + 3 * 128;
+constexpr int kMcStagger = 0;                // s_sleep(127) rounds of the second workgroup of a CU before its first pair
 
 // float offset of tap t inside a padded plane (taps 49..51 are padding: weight 0, any valid address)
 __host__ __device__ constexpr int tap_offset(int t) { return t < 49 ? (t / 7) * kMcW + (t % 7) : 0; }
@@ -34,12 +38,12 @@ __host__ __device__ constexpr int tap_offset(int t) { return t < 49 ? (t / 7) * 
 __global__ void __launch_bounds__(256, 2)
 mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restrict__ mask_off, const float* __restrict__ w0p,
                        const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
-                       float* __restrict__ c2, int P) {
+                       float* __restrict__ c2, int P, int stagger) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
   float* mbuf = lds;                                                   // [2][kMcMask], double-buffered
-  float* pool = lds + 2 * kMcMask + wave * (kMcPoolCh * 196);         // wave-private [8][196]
-  float* par = lds + 2 * kMcMask + 4 * kMcPoolCh * 196;               // bias | scale | shift, [3][128]
+  float* pool = lds + 2 * kMcMask + wave * (kMcPoolCh * kMcPoolPlane); // wave-private [8][15][15], row 0 / column 0 = -inf
+  float* par = lds + 2 * kMcMask + 4 * kMcPoolCh * kMcPoolPlane;       // bias | scale | shift, [3][128]
 
   // weights of this lane: channel 32*wave + fr, k = (group, half, e)  (w0p is [128][104] in that order)
   f32x4 a[kMcGroups];
@@ -56,15 +60,29 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
   }
   // pooling map of this lane: output o = lane + 64 i of the round's 49 x 8 block, channel fastest (the result is
   // stored channel-last, [pair][7][7][128], so that the 3x3 convolution behind it gathers 4 channels per load)
+  // The 3x3 / stride-2 / padding-1 window of output (py, px) covers conv rows 2py-1 .. 2py+1 and columns 2px-1 .. 2px+1;
+  // with the -inf border row / column in front of the map every window is nine unconditional reads at pbase + {0,1,2} +
+  // {0,15,30} (MaxPool2d pads with -inf, lib/sttran.py:341).
   int pbase[7], pdst[7];
-  unsigned pmask = 0;                                                  // bit 2i: row above exists, bit 2i+1: column left exists
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const int o = lane + 64 * i, oo = o < kMcPoolCh * 49 ? o : 0;
     const int pos = oo / kMcPoolCh, ch = oo - pos * kMcPoolCh, py = pos / 7, px = pos - py * 7;
-    pbase[i] = ch * 196 + 2 * py * 14 + 2 * px;
+    pbase[i] = ch * kMcPoolPlane + 2 * py * kMcPoolW + 2 * px;
     pdst[i] = pos * 128 + ch;
-    pmask |= (py > 0 ? 1u : 0u) << (2 * i) | (px > 0 ? 1u : 0u) << (2 * i + 1);
+  }
+  // where this lane's conv outputs go: column n = 32 j + fr of the 14 x 14 map -> (row + 1, column + 1) of the bordered plane
+  // (= n + n / 14 + 16; the seven quotients n / 14 <= 13 ride in one register, four bits each)
+  unsigned pwq = 0;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int n = 32 * j + fr;
+    pwq |= (unsigned)((n < 196 ? n : 0) / 14) << (4 * j);
+  }
+  const int pw0 = fr + kMcPoolW + 1;
+  for (int i = lane; i < kMcPoolCh * (2 * kMcPoolW - 1); i += 64) {    // the border of the wave's eight planes, once
+    const int ch = i / (2 * kMcPoolW - 1), r = i - ch * (2 * kMcPoolW - 1);
+    pool[ch * kMcPoolPlane + (r < kMcPoolW ? r : (r - kMcPoolW + 1) * kMcPoolW)] = -INFINITY;
   }
 
   for (int i = tid; i < 2 * kMcMask; i += 256) mbuf[i] = 0.f;          // the padding stays zero for good
@@ -87,6 +105,18 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
   }
   __syncthreads();
 
+  // STAGGER.  Two workgroups share a CU (one wave of each per SIMD) and run the same program on equal work: started
+  // together they stay in lockstep -- both in their MFMA phase (the matrix pipe shared), then both in their epilogue
+  // (activation, pooling through LDS, stores: vector ALU and LDS only, the matrix pipe idle: it was busy 63 % of the
+  // kernel, r5 PMC).  The workgroup that was placed SECOND on its CU (its LDS allocation does not start at 0) sleeps
+  // for about one MFMA phase before its first pair; the offset then persists (neither workgroup gains on the other in
+  // a period), so one's epilogue runs under the other's MFMAs.
+  if (stagger > 0) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 6);     // HW_REG_LDS_ALLOC.LDS_BASE
+    if (lds_base != 0)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);                       // 127 x 64 clocks each
+  }
+
   for (int it = 0; p < P; p += gridDim.x, ++it) {
     const float* cur = mbuf + (it & 1) * kMcMask;
     float* nxt = mbuf + ((it + 1) & 1) * kMcMask;
@@ -104,15 +134,41 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    // K loop in units of two taps (one ds_read2_b32 per column block and unit: both tap offsets are immediates), software-
+    // pipelined by hand: the 7 reads of unit u + 1 are issued between the 14 MFMAs of unit u (one read per two MFMAs), so a
+    // wave alone keeps the matrix pipe fed -- hipcc's own schedule of the plain loop nest read, waited for lgkmcnt(0) and
+    // issued two or three MFMAs, 180 times per pair (r5: matrix pipe busy 63 % of the kernel).  Taps 50 and 51 (zero
+    // weights: K is padded to groups of 4 for the register layout of `a`) are not executed: 25 units, 350 MFMAs.
+    constexpr int kUnits = 25;
+    float bq[2][7][2];
 #pragma unroll
-    for (int g = 0; g < kMcGroups; ++g)
+    for (int j = 0; j < 7; ++j) {
+      bq[0][j][0] = cur[lb[j] + tap_offset(0)];
+      bq[0][j][1] = cur[lb[j] + tap_offset(1)];
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int off = tap_offset(g * 4 + e);
+    for (int u = 0; u < kUnits; ++u) {
+      if (u + 1 < kUnits) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          bq[(u + 1) & 1][j][0] = cur[lb[j] + tap_offset(2 * u + 2)];
+          bq[(u + 1) & 1][j][1] = cur[lb[j] + tap_offset(2 * u + 3)];
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int j = 0; j < 7; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][e], cur[lb[j] + off], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(2 * u + tt) >> 2][(2 * u + tt) & 3], bq[u & 1][j][tt], acc[j], 0, 0, 0);
+      if (u + 1 < kUnits) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // bias -> ReLU -> BN, then 3x3/2 max pooling, 8 channels of this wave at a time.
     // accumulator register 4q + r of column block j = channel 8q + r + 4*half, position 32j + fr
@@ -131,7 +187,8 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
         if (n < 196) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pool[(r + 4 * fh) * 196 + n] = relu_nan(acc[j][4 * q + r] + cb[r]) * cs[r] + ct[r];
+            pool[(r + 4 * fh) * kMcPoolPlane + pw0 + 32 * j + (int)((pwq >> (4 * j)) & 15u)] =
+                relu_nan(acc[j][4 * q + r] + cb[r]) * cs[r] + ct[r];
         }
       }
       // `pool` is private to this wave and a wave's LDS operations execute in program order: the lanes' writes above are
@@ -145,12 +202,19 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
         const int o = lane + 64 * i;
         if (o < kMcPoolCh * 49) {
           const float* s = pool + pbase[i];
-          const bool up = (pmask >> (2 * i)) & 1u, left = (pmask >> (2 * i + 1)) & 1u;
-          float m = max_nan(max_nan(s[0], s[1]), max_nan(s[14], s[15]));
-          if (left) m = max_nan(m, max_nan(s[-1], s[13]));
-          if (up) m = max_nan(m, max_nan(s[-14], s[-13]));
-          if (up && left) m = max_nan(m, s[-15]);
-          dst[q * kMcPoolCh + pdst[i]] = m;
+          const float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[kMcPoolW], s4 = s[kMcPoolW + 1], s5 = s[kMcPoolW + 2],
+                      s6 = s[2 * kMcPoolW], s7 = s[2 * kMcPoolW + 1], s8 = s[2 * kMcPoolW + 2];
+          // NaN-propagating maximum of the nine (torch's max_pool2d returns NaN if the window holds one): three v_max3 +
+          // one, and five unordered compares -- not eight compare / select chains
+          // (inline asm: fmaxf() makes hipcc canonicalise every loaded operand with a v_max_f32 x, x first)
+          float m0, m1, m2, m;
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(s0), "v"(s1), "v"(s2));
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(s3), "v"(s4), "v"(s5));
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(s6), "v"(s7), "v"(s8));
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m0), "v"(m1), "v"(m2));
+          const bool un = __builtin_isunordered(s0, s1) | __builtin_isunordered(s2, s3) | __builtin_isunordered(s4, s5) |
+                          __builtin_isunordered(s6, s7) | __builtin_isunordered(s8, s8);
+          dst[q * kMcPoolCh + pdst[i]] = un ? __builtin_nanf("") : m;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next round's writes stay behind these reads
@@ -180,7 +244,9 @@ hipError_t launch_mask_conv1_pool(hipStream_t s, const float* masks, const int64
   hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(mask_conv1_pool_kernel), lds_bytes);
   if (e != hipSuccess) return e;
   const int grid = std::min(P, 2 * std::max(num_cus(), 1));
-  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, mask_off, w0p, bias, scale, shift, c2, P);
+  static const int stagger = [] { const char* e = exp_env("STTRAN_MC_STAGGER"); return e ? atoi(e) : kMcStagger; }();
+  hipLaunchKernelGGL(mask_conv1_pool_kernel, dim3(grid), dim3(256), lds_bytes, s, masks, mask_off, w0p, bias, scale, shift, c2, P,
+                     P > grid ? stagger : 0);
   return hipGetLastError();
 }
 
