@@ -811,14 +811,18 @@ int sttran_finalize_weights(SttranHandle* h) {
     if ((rc = bn("object_classifier.pos_embed.0", 4, h->oc_pos_scale, h->oc_pos_shift))) return rc;
     if ((rc = bn("object_classifier.decoder_lin.1", 1024, h->oc_bn_scale, h->oc_bn_shift))) return rc;
   }
-  // conv.0.weight [128][ci 2][tap 49] -> [128][group 13][ci 2][tap-in-group 4] (taps 49..51 zero): the K order
-  // of mask_conv1_pool_kernel, whose lane halves carry the two input channels
+  // conv.0.weight [128][ci 2][tap 49] -> [128][group 13][ci 2][tap-in-group 4]: the K order of mask_conv1_pool_kernel,
+  // whose lane halves carry the two input channels.  Tap 49 is the BIAS tap (the kernel feeds it the operand 1.0): weight
+  // (conv.0.bias[co], 0) for the two halves; taps 50, 51 stay zero and are not executed.
   {
-    std::vector<float> w(128 * 98), wp(128 * 104, 0.f);
+    std::vector<float> w(128 * 98), wp(128 * 104, 0.f), b0(128);
     HIPCK(hipMemcpy(w.data(), W(h, "conv.0.weight"), w.size() * 4, hipMemcpyDeviceToHost));
-    for (int co = 0; co < 128; ++co)
+    HIPCK(hipMemcpy(b0.data(), W(h, "conv.0.bias"), b0.size() * 4, hipMemcpyDeviceToHost));
+    for (int co = 0; co < 128; ++co) {
       for (int ci = 0; ci < 2; ++ci)
         for (int t = 0; t < 49; ++t) wp[(size_t)co * 104 + (t / 4) * 8 + ci * 4 + (t % 4)] = w[(size_t)co * 98 + ci * 49 + t];
+      wp[(size_t)co * 104 + (49 / 4) * 8 + 0 * 4 + (49 % 4)] = b0[co];
+    }
     HIPCK(hipMemcpy(h->w0_perm, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
   }
   // conv.4.weight [256][ci 128][ky 3][kx 3] -> [256][(ky, kx)][ci]: the K order of the B_CONV2 loader
