@@ -25,6 +25,9 @@
 
 namespace sttran {
 
+// four floats at a 4-byte aligned address: global memory takes a dwordx4 access at any dword address (unaligned access mode)
+struct __attribute__((packed, aligned(4))) V4a4 { f32x4 v; };
+
 template <int BKIND_>
 struct Tile16C {
   static constexpr int BM = 256, BN = 128, BKIND = BKIND_;
@@ -265,22 +268,72 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       for (int i = 0; i < BV; ++i) asm volatile("" ::"v"(rbx[0][i]), "v"(rbx[1][i]));
     }
     if (nsteps == ksteps) {
-      // whole tile: per-channel constants first (8 channels per lane), then only stores
+      // Whole tile.  Round 3-4 stored straight from the accumulators: a lane holds four CHANNELS of one column, so a store
+      // instruction wrote 4 x 64 contiguous bytes (16 hw of 4 channels) and a tile took 64 dword stores per lane (2.8-4.3 % of
+      // the kernel by ablation).  Now the finished values cross the wave's own LDS block (16 channels x 128 columns per pass,
+      // rows 132 floats apart) and leave as 16-byte pieces of four consecutive hw: a [49]-float row of V starts at any
+      // multiple of 4 bytes, which global memory takes for a dwordx4 access.  A piece that would run over a pair's last hw
+      // (the tile's columns run straight over the pair borders: at most three such pieces in 128 columns) or over column N
+      // is left out of the 16-byte pass; those few pieces x 16 channels are spread over the lanes of a second, dword pass.
+      constexpr int EPS = BN + 4;                        // floats per LDS row: 528 bytes = 33 sixteen-byte slots
+      static_assert(8 * 16 * EPS * 4 <= T::LDS_BYTES, "eight wave blocks fit the stage buffers");
       typename Epi::Consts cst[2][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int v = 0; v < 4; ++v) cst[i][v] = epi.consts(ch0 + 16 * i + v);
+      // this lane's piece of every row it handles: columns n0 + 4 q .. + 3
+      const int q = lane & 31, c0 = n0 + 4 * q;
+      const int pq = c0 / kUHW, hwq = c0 - pq * kUHW;
+      const bool whole = hwq + 3 < kUHW && c0 + 3 < N;  // inside one pair, inside the operand
+      float* const vq = whole ? epi.addr(m0 + wave * 32 + (lane >> 5), c0) : nullptr;
+      // the pieces left to the dword pass: the one before every pair border inside the tile (unless the border falls on a
+      // piece border) and the one that holds column N
+      int odd[4], nodd = 0;
+      {
+        const int b0 = (n0 + kUHW - 1) / kUHW * kUHW;   // first pair border >= n0
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int col = colb + 16 * j;
-        if (col < N && (ABL != 7 || acc[0][j][0] == 12345.678f)) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) epi.store(ch0 + 16 * i + v, col, acc[i][j][v], cst[i][v]);
+        for (int k = 0; k < 3; ++k) {
+          const int b = b0 + k * kUHW, r = b - n0;
+          if (r < BN && b < N && (r & 3)) odd[nodd++] = r >> 2;
         }
+        if (N - n0 < BN && N > n0 && ((N - n0) & 3)) odd[nodd++] = (N - n0) >> 2;
       }
+      __syncthreads();                                   // every wave is done with the stage buffers
+      float* const ep = smem + wave * (16 * EPS);
+      const bool keep = ABL != 7 || acc[0][0][0] == 12345.678f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) ep[(4 * fg + v) * EPS + 16 * j + fr] = epi.value(acc[i][j][v], cst[i][v]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the block is private to this wave: program order is enough
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (whole && keep) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {                  // rows (lane >> 5) + 2 u of the pass, 16 bytes each
+            const f32x4 val = *reinterpret_cast<const f32x4*>(ep + ((lane >> 5) + 2 * u) * EPS + 4 * q);
+            reinterpret_cast<V4a4*>(vq + (int64_t)(16 * i + 2 * u) * kUHW)->v = val;
+          }
+        }
+        if (nodd && keep) {                              // (item = odd piece x row) per lane, four dword stores each
+          for (int it = lane; it < nodd * 16; it += 64) {
+            const int k = it >> 4, r = it & 15, qq = k == 0 ? odd[0] : k == 1 ? odd[1] : k == 2 ? odd[2] : odd[3];
+            const f32x4 val = *reinterpret_cast<const f32x4*>(ep + r * EPS + 4 * qq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int col = n0 + 4 * qq + e;
+              if (col < N) *epi.addr(m0 + wave * 32 + 16 * i + r, col) = val[e];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next pass's writes stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      __syncthreads();                                   // the next tile's first K-step is staged over these blocks
     } else {
       f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
 #pragma unroll
@@ -342,17 +395,21 @@ struct EpiUnionT16 {
   }
   __device__ __forceinline__ float init(int row, int col) const { return *at(row, col); }
   __device__ __forceinline__ Consts consts(int row) const { return Consts{bias[row]}; }
-  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const { *at(row, col) = v + c.b; }
+  __device__ __forceinline__ float value(float v, const Consts& c) const { return v + c.b; }
+  __device__ __forceinline__ float* addr(int row, int col) const { return at(row, col); }
+  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const { *at(row, col) = value(v, c); }
 };
 // conv3x3: ReLU, then eval-mode BatchNorm (lib/sttran.py:342-344), channel-major into V[p][c][hw]
 struct EpiConvT16 {
   float* V; const float* bias; const float* scale; const float* shift; int C;
   struct Consts { float b, s, t; };
   __device__ __forceinline__ Consts consts(int row) const { return Consts{bias[row], scale[row], shift[row]}; }
-  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const {
+  __device__ __forceinline__ float value(float v, const Consts& c) const { return relu_nan(v + c.b) * c.s + c.t; }
+  __device__ __forceinline__ float* addr(int row, int col) const {
     const int p = col / kUHW, hw = col - p * kUHW;
-    V[((int64_t)p * C + row) * kUHW + hw] = relu_nan(v + c.b) * c.s + c.t;
+    return V + ((int64_t)p * C + row) * kUHW + hw;
   }
+  __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const { *addr(row, col) = value(v, c); }
 };
 
 }  // namespace sttran
