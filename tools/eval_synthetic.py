@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--evaluator", choices=("hip", "host"), default="hip",
                     help="hip: per-frame matching on the GPU (sttran_eval_recall); host: the numpy evaluator")
     ap.add_argument("--lanes", type=int, default=3, help="clips in flight on the handle's lanes (1 = the serial loop)")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="model.coalesce: every K one-clip calls are issued as one by-pointer forward on a lane (0 = off)")
     ap.add_argument("--merge", choices=("tallies", "gather"), default="tallies")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,6 +83,8 @@ def main():
         return ev
     own = evaluator() if a.merge == "tallies" or world == 1 else None
     model.lanes = a.lanes
+    model.coalesce = a.coalesce
+    depth = model.pipeline_depth if a.coalesce > 1 else a.lanes
     rows, t0, frames = {}, time.perf_counter(), 0
     pending = collections.deque()
 
@@ -94,9 +98,9 @@ def main():
         for i in mine:
             e = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) and k != "frame_counts" else v)
                  for k, v in entries[i].items()}
-            pending.append((i, model.forward_async(e) if a.lanes > 1 else model(e)))
+            pending.append((i, model.forward_async(e) if a.lanes > 1 or a.coalesce > 1 else model(e)))
             frames += len(shapes[i])
-            if len(pending) >= a.lanes:
+            if len(pending) >= depth:
                 consume(*pending.popleft())
         while pending:
             consume(*pending.popleft())

@@ -39,11 +39,14 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do pmc dsg $c --model dsgdetr --steps 3 --warmup 1; done
 python3 tools/pmc_traffic.py "$O/${P}_pmc_dsg_FETCH_SIZE" "$O/${P}_pmc_dsg_WRITE_SIZE" "$C" 64 > "$O/${P}_pmc_traffic_dsgdetr_16x12.json"
 # 3. MFMA-pipe occupancy of the dominant kernels (one counter per pass)
-for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY; do pmc busy $c --steps 3 --warmup 1; done
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU; do pmc busy $c --steps 3 --warmup 1; done
 for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "EpiUnionT16" "EpiConvT16"; do
   tag=$(echo "$k" | tr -c 'A-Za-z0-9' '_' | cut -c1-40)
   python3 tools/pmc_mfma_busy.py "$O/${P}_pmc_busy_" "$k" "$C" > "$O/${P}_pmc_mfma_busy_$tag.json"
 done
+# ... and of every kernel class of the step side by side, the non-GEMM kernels included (round 5)
+python3 tools/pmc_kernels.py "$O/${P}_pmc_busy_" "$C" mask_conv1_pool_kernel attention_short_kernel layernorm_kernel EpiUnionT16 EpiConvT16 \
+  "Tile16<128, 176>" "Tile16<128, 128>" > "$O/${P}_pmc_kernels.json"
 # 4. bench lines (unprofiled)
 # (stdout = the one compact line the driver parses; the full object goes to $BENCH_DETAIL)
 BENCH_DETAIL="$O/${P}_bench_default_detail.json" python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
@@ -56,6 +59,8 @@ python3 bench.py --clips-per-step 16 --no-cpu-baseline --no-extra-workloads --de
 python3 bench.py --model dsgdetr --no-cpu-baseline --detail "$O/${P}_bench_dsgdetr_16x12_detail.json" > "$O/${P}_bench_dsgdetr_16x12.json" 2>/dev/null
 python3 bench.py --model dsgdetr --workload 64x36 --steps 10 --no-cpu-baseline --detail "$O/${P}_bench_dsgdetr_64x36_detail.json" > "$O/${P}_bench_dsgdetr_64x36.json" 2>/dev/null
 python3 tools/ag_split_bench.py > "$O/${P}_ag_split_shaped.json" 2>/dev/null
+# RCCL itself on this one GPU: a one-rank nccl group under the gather / all-reduce / barrier code of the N > 1 legs
+python3 bench.py --gpus 1 --rccl-selftest > "$O/${P}_rccl_selftest.json" 2> "$O/${P}_rccl_selftest.err" || true
 # two ranks on this one GPU over gloo (the N > 1 code path, self-launched): what the 8-GPU driver run will execute
 BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline \
   --detail "$O/${P}_bench_2ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
