@@ -414,11 +414,6 @@ class Env:
         self.local = int(os.environ.get("BENCH_FORCE_DEVICE", local))
         ndev = torch.cuda.device_count()
         forced = "BENCH_FORCE_DEVICE" in os.environ
-        if not forced and ndev == 1 and self.world > 1 and any(os.environ.get(v) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES",
-                                                                                             "CUDA_VISIBLE_DEVICES")):
-            # a launcher that narrows every rank to ITS OWN GPU (one visible device per process, LOCAL_RANK still 0..N-1):
-            # the rank's device is ordinal 0 of what it sees
-            self.local, forced = 0, True
         missing = [r for r in range(self.world) if r >= ndev] if not forced else ([self.rank] if self.local >= ndev else [])
         if missing:
             # A mis-provisioned run (fewer GPUs than ranks; one node: LOCAL_RANK = ordinal) must still leave a parseable
