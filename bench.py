@@ -918,6 +918,16 @@ def run_workload(env, model, model_kind, workload, cps, steps, warmup, *, graph=
 COMPACT_LIMIT = 4096
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio, which is block-buffered when stdout is a pipe or a file and would then
+    be written at process exit -- BEHIND the JSON line.  Flush it out before the line is printed, so the line stays last."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def error_line(args, world, msg):
     """A compact line for a run that could not start (no device for a rank): every contract key, value 0, and `error`."""
     return json.dumps({"metric": "frames/sec (PredCls inference)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
@@ -1158,6 +1168,7 @@ def main():
             st = rccl_selftest(env, model)
         except Exception as e:
             st = {"ok": False, "error": repr(e)[:300]}
+        flush_c_stdio()
         print(json.dumps({"rccl_selftest": st}), flush=True)
         try:
             env.dist.destroy_process_group()
@@ -1318,6 +1329,15 @@ def main():
             # the other clip shape's CPU number, on the thread count that won above (one warm-up + one timed forward)
             result["workloads"][other]["cpu_baseline"] = cpu_baseline(*SHAPES[other][:2], sd, budget_s=14.0,
                                                                       threads=result["cpu_baseline"]["cores"])
+    # RCCL writes a version banner through C stdio (block-buffered on a pipe: it would come out at process exit, BEHIND the
+    # JSON line) -- every rank flushes it now, ranks other than 0 then close their stdout for good, and rank 0 does the same
+    # right behind the line: the line is the LAST thing on the job's stdout whatever the libraries print at teardown.
+    flush_c_stdio()
+    sys.stdout.flush()
+    if rank != 0:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if world > 1:
+        env.barrier()
     if rank == 0:
         # The FULL object (per-kernel and per-shape tables, per-rank records, notes; ~25 KB) goes to a side file and to
         # stderr; stdout carries ONE compact line of scalars (< 4 KB) -- the driver keeps the last 8 KB of stdout and
@@ -1328,7 +1348,9 @@ def main():
         except OSError as e:
             print(f"bench.py: could not write {args.detail}: {e}", file=sys.stderr)
         print("BENCH_DETAIL " + json.dumps(result), file=sys.stderr, flush=True)
+        flush_c_stdio()
         print(compact_line(result), flush=True)
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world > 1:
         env.barrier()
         # the line is out; a communicator teardown that does not come back must not keep the launcher (and the driver's
