@@ -419,7 +419,38 @@ attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ se
 }
 
 // dynamic-LDS limits already raised per device, shared by both launchers (a second set of marks could LOWER a limit)
-static DeviceMarks g_attn_marks[3], g_attn_marks_long;
+static DeviceMarks g_attn_marks[5], g_attn_marks_long;
+
+// The short-sequence variants (round 5: chosen by LENGTH and by how many workgroups the launch has).
+//   V_E32  <128,256,32,4,EARLY>  <= 32 keys, every global load issued up front: ONE memory wait per workgroup -- the lowest
+//          latency, 38 KB of LDS and 123 registers = four workgroups per CU.  Kept where latency decides: launches with too few
+//          workgroups to fill the chip (one clip per call), and full 25 .. 32-key sequences (660 x 32: 142 vs 149 us).
+//   V_C32  <64,128,32,8>         <= 24 keys in a launch that fills the chip: head-dim chunks of 64, V in two halves -- 22 KB of
+//          LDS and 60 registers = SEVEN workgroups per CU; more round trips per workgroup, but with ~22 keys a workgroup is
+//          nothing but round trips and the extra residents cover them: 1 024 x 11 keys 99 -> 84 us, 960 x 22 162 -> 153 us in
+//          situ (ms_attention 0.541 -> 0.504 per step).
+//   V_C48  <64,128,48,4>         33 .. 48 keys, always: 36 KB of LDS instead of the 60 KB of the <128,256> form it replaces, i.e.
+//          four workgroups per CU instead of two: 256 x 35 keys (the 64x36 encoder) 120 -> 90 us.
+//   V_80   <64,128,80,2>         49 .. 80 keys (70 KB, two workgroups per CU), unchanged.
+enum { V_E32 = 0, V_C32 = 1, V_C48 = 2, V_80 = 3 };
+static int short_variant(int len, int64_t workgroups) {
+  if (len > 48) return V_80;
+  if (len > 32) return V_C48;
+  return (len <= 24 && workgroups >= (int64_t)7 * std::max(num_cus(), 1)) ? V_C32 : V_E32;
+}
+static int short_lds_bytes(int variant, int l16) {
+  const int cs = (variant == V_E32 ? 128 : 64) + 4, vs = (variant == V_E32 ? 256 : 128) + 4;
+  return (std::max(2 * l16 * cs, l16 * vs) + l16 * (l16 + 4)) * 4;
+}
+using ShortKernel = void (*)(const float*, const int*, const int*, const int*, float*, int64_t, int, int, float, int, int, int);
+static ShortKernel short_kernel(int variant) {
+  switch (variant) {
+    case V_E32: return attention_short_kernel<128, 256, 32, 4, true>;
+    case V_C32: return attention_short_kernel<64, 128, 32, 8>;
+    case V_C48: return attention_short_kernel<64, 128, 48, 4>;
+    default: return attention_short_kernel<64, 128, kAttnShortMax, 2>;
+  }
+}
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,
                             const int* q_begin, int num_seq, int max_len, float* out, int64_t ldo, int dim, int nhead) {
@@ -429,14 +460,10 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
   const float scale = 1.0f / sqrtf((float)hd);
   if (max_len <= kAttnShortMax) {
     const int l16 = (max_len + 15) & ~15;
-    const bool small = l16 <= 48;
-    const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
-    const int region = std::max(2 * l16 * cs, l16 * vs);
-    const int lds = (region + l16 * (l16 + 4)) * 4;
-    const bool early = l16 <= 32;                      // every operand of a workgroup fits its registers: one memory wait
-    auto kern = early ? attention_short_kernel<128, 256, 32, 4, true>
-                      : small ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    hipError_t e = g_attn_marks[early ? 2 : small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    const int var = short_variant(max_len, (int64_t)num_seq * nhead);
+    const int lds = short_lds_bytes(var, l16);
+    auto kern = short_kernel(var);
+    hipError_t e = g_attn_marks[var].raise_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, q_begin, out, ldo, dim,
                        hd, scale, l16, 0, 1 << 30);
@@ -466,15 +493,14 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
   const int edges[4] = {0, 32, 48, kAttnShortMax};
   for (int v = 0; v < 3; ++v) {
     if (len_bound <= edges[v]) break;
-    const bool small = v < 2;
     const int hi = edges[v + 1];
-    const int l16 = ((std::min(len_bound, hi) + 15) & ~15);
-    const int cs = (small ? 128 : 64) + 4, vs = (small ? 256 : 128) + 4;
-    const int region = std::max(2 * l16 * cs, l16 * vs);
-    const int lds = (region + l16 * (l16 + 4)) * 4;
-    auto kern = v == 0 ? attention_short_kernel<128, 256, 32, 4, true>
-                       : v == 1 ? attention_short_kernel<128, 256, 48, 4> : attention_short_kernel<64, 128, kAttnShortMax, 2>;
-    hipError_t e = g_attn_marks[v == 0 ? 2 : small].raise_lds(reinterpret_cast<const void*>(kern), lds);
+    const int top = std::min(len_bound, hi), l16 = (top + 15) & ~15;
+    // (every slot gets a workgroup in every class launch; most return at once: the count says little about the load, so
+    // the <= 32 class is chosen by the bound alone -- DSG-DETR's class sequences are at most one token per frame of a clip)
+    const int var = v == 0 ? (top <= 24 ? V_C32 : V_E32) : v == 1 ? V_C48 : V_80;
+    const int lds = short_lds_bytes(var, l16);
+    auto kern = short_kernel(var);
+    hipError_t e = g_attn_marks[var].raise_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nhead, num_seq), dim3(256), lds, s, qkv, seq_off, seq_len, (const int*)nullptr, out, ldo, dim,
                        hd, scale, l16, edges[v], hi);
