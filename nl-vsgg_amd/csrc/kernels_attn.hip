@@ -215,9 +215,9 @@ __device__ __forceinline__ void stage_store4(float* dst, int dstride, const f32x
     if (i < total) *reinterpret_cast<f32x4*>(dst + r * dstride + c4) = v[u] * scale;
   }
 }
-// CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2.  <64,128> needs 70 KB at
-// 80 keys (two workgroups per CU: long windows); <128,256> has half the barriers and is used while the
-// sequences are so short (<= 48 keys) that LDS does not limit residency anyway.
+// CHUNK = head-dim chunk of phase 1, VW = V columns staged per pass of phase 2: smaller chunks = more barriers and
+// round trips per workgroup, but less LDS and fewer registers, i.e. more resident workgroups to cover them.  Which
+// instantiation serves which launch: short_variant() below (round 5: residency wins wherever the launch fills the chip).
 template <int CHUNK, int VW, int MAXROWS, int MINWG, bool EARLY = false>
 __global__ void __launch_bounds__(256, MINWG)
 attention_short_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
@@ -431,7 +431,9 @@ static DeviceMarks g_attn_marks[5], g_attn_marks_long;
 //          situ (ms_attention 0.541 -> 0.504 per step).
 //   V_C48  <64,128,48,4>         33 .. 48 keys, always: 36 KB of LDS instead of the 60 KB of the <128,256> form it replaces, i.e.
 //          four workgroups per CU instead of two: 256 x 35 keys (the 64x36 encoder) 120 -> 90 us.
-//   V_80   <64,128,80,2>         49 .. 80 keys (70 KB, two workgroups per CU), unchanged.
+//   V_80   <32,64,80,3>          49 .. 80 keys: head-dim chunks of 32, V in quarters -- 50 KB of LDS (the 27 KB score block
+//          included) instead of the 70 KB of <64,128>, three workgroups per CU instead of two: 252 x 70 keys (the 64x36
+//          decoder windows) 243 -> 230 us.
 enum { V_E32 = 0, V_C32 = 1, V_C48 = 2, V_80 = 3 };
 static int short_variant(int len, int64_t workgroups) {
   if (len > 48) return V_80;
@@ -439,7 +441,7 @@ static int short_variant(int len, int64_t workgroups) {
   return (len <= 24 && workgroups >= (int64_t)7 * std::max(num_cus(), 1)) ? V_C32 : V_E32;
 }
 static int short_lds_bytes(int variant, int l16) {
-  const int cs = (variant == V_E32 ? 128 : 64) + 4, vs = (variant == V_E32 ? 256 : 128) + 4;
+  const int cs = (variant == V_E32 ? 128 : variant == V_80 ? 32 : 64) + 4, vs = (variant == V_E32 ? 256 : variant == V_80 ? 64 : 128) + 4;
   return (std::max(2 * l16 * cs, l16 * vs) + l16 * (l16 + 4)) * 4;
 }
 using ShortKernel = void (*)(const float*, const int*, const int*, const int*, float*, int64_t, int, int, float, int, int, int);
@@ -448,7 +450,7 @@ static ShortKernel short_kernel(int variant) {
     case V_E32: return attention_short_kernel<128, 256, 32, 4, true>;
     case V_C32: return attention_short_kernel<64, 128, 32, 8>;
     case V_C48: return attention_short_kernel<64, 128, 48, 4>;
-    default: return attention_short_kernel<64, 128, kAttnShortMax, 2>;
+    default: return attention_short_kernel<32, 64, kAttnShortMax, 3>;
   }
 }
 
