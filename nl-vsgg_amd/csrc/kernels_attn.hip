@@ -497,9 +497,11 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     if (len_bound <= edges[v]) break;
     const int hi = edges[v + 1];
     const int top = std::min(len_bound, hi), l16 = (top + 15) & ~15;
-    // (every slot gets a workgroup in every class launch; most return at once: the count says little about the load, so
-    // the <= 32 class is chosen by the bound alone -- DSG-DETR's class sequences are at most one token per frame of a clip)
-    const int var = v == 0 ? (top <= 24 ? V_C32 : V_E32) : v == 1 ? V_C48 : V_80;
+    // The <= 32 class: the bound says little here (DSG-DETR's bound is the pairs of a clip, its class sequences average
+    // pairs / classes ~ 5 tokens): a launch with enough slots to fill the chip takes the high-residency form whatever the
+    // bound (correct up to 32 keys like V_E32; full 25..32-key sequences would be ~5 % slower on it), a small one V_E32
+    const bool dense = (int64_t)num_seq * nhead >= (int64_t)7 * std::max(num_cus(), 1);
+    const int var = v == 0 ? ((top <= 24 || dense) ? V_C32 : V_E32) : v == 1 ? V_C48 : V_80;
     const int lds = short_lds_bytes(var, l16);
     auto kern = short_kernel(var);
     hipError_t e = g_attn_marks[var].raise_lds(reinterpret_cast<const void*>(kern), lds);
