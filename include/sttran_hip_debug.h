@@ -72,7 +72,7 @@ int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int6
                             int32_t* dec_len, int32_t* dec_src, int32_t* need, int32_t* out_src, int32_t* scratch4p,
                             int32_t* err_flag, void* stream);
 /* sttran_debug_attention for sequences whose lengths only the device knows: len_bound >= every seq_len[i]; one launch per
- * length class ((0,48], (48,80], (80,len_bound]), empty slots allowed. */
+ * length class ((0,32], (32,80], (80,len_bound]), empty slots allowed. */
 int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
                                    int32_t len_bound, float* out, int32_t dim, int32_t nhead, void* stream);
 

@@ -48,10 +48,15 @@ __global__ void __launch_bounds__(256)
 attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off, const int* __restrict__ seq_len,
                  float* __restrict__ out, int64_t ldo, int dim, int hd, float scale, int kc, int len_lo, int len_hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 32;
+  const int s = blockIdx.z, h = blockIdx.y;
   const int L = seq_len[s];
   // (len_lo, len_hi]: shorter sequences belong to another launch (launch_attention_classes)
-  if (q0 >= L || L <= len_lo || L > len_hi) return;
+  if (L <= len_lo || L > len_hi) return;
+  // query tiles of this workgroup: blockIdx.x, + gridDim.x, ...  launch_attention gives every 32-query tile its own
+  // workgroup; launch_attention_classes (lengths known on the device only: most slots of a launch are empty or belong to
+  // another class) launches ONE workgroup per (head, slot) that walks the tiles -- an empty slot then costs one workgroup,
+  // not ceil(bound / 32) of them (DSG-DETR: the all-empty (80, 176] launch 54 -> 9 us, three of them per step)
+  for (int q0 = blockIdx.x * 32; q0 < L; q0 += gridDim.x * 32) {
   const int base = seq_off[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ps = kc + 4;                        // score row stride
@@ -159,6 +164,8 @@ attention_kernel(const float* __restrict__ qkv, const int* __restrict__ seq_off,
       if (c0 < hd) op[(int64_t)q * ldo + c0] = o0[e] * ri;
       if (c1 < hd) op[(int64_t)q * ldo + c1] = o1[e] * ri;
     }
+  }
+  __syncthreads();                              // rsum / Qs are rewritten by the next query tile
   }
 }
 
@@ -483,17 +490,19 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off,
 }
 
 // The same attention when the host does NOT know the sequence lengths (DSG-DETR's class sequences are built on the
-// device): `len_bound` >= every length.  One launch per length class the bound allows -- (0, 32], (32, 48] and (48, 80] on the
-// three short-sequence variants, (80, bound] on the general kernel --, each over all `num_seq` slots; a workgroup whose
-// sequence is empty or belongs to another class returns at once.  No read-back, capturable.
+// device): `len_bound` >= every length.  One launch per length class the bound allows -- (0, 32] and (32, 80] on the
+// short-sequence variants, (80, bound] on the general kernel with one workgroup per (head, slot) --, each over all `num_seq`
+// slots; a workgroup whose sequence is empty or belongs to another class returns at once.  No read-back, capturable.
 hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len, int num_seq,
                                     int len_bound, float* out, int64_t ldo, int dim, int nhead) {
   if (num_seq <= 0 || len_bound <= 0) return hipSuccess;
   const int hd = dim / nhead;
   if (hd > kHdPad - 2 || (hd & 1) || hd < 4 || (ldo & 1)) return hipErrorInvalidValue;
   const float scale = 1.0f / sqrtf((float)hd);
-  const int edges[4] = {0, 32, 48, kAttnShortMax};
-  for (int v = 0; v < 3; ++v) {
+  // classes: (0, 32], (32, 80] on the 80-key variant (one launch for both upper short classes: in the launches this entry
+  // point serves they are empty or nearly so, and an empty launch costs ~9 us), (80, bound] on the general kernel
+  const int edges[3] = {0, 32, kAttnShortMax};
+  for (int v = 0; v < 2; ++v) {
     if (len_bound <= edges[v]) break;
     const int hi = edges[v + 1];
     const int top = std::min(len_bound, hi), l16 = (top + 15) & ~15;
@@ -501,7 +510,7 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     // pairs / classes ~ 5 tokens): a launch with enough slots to fill the chip takes the high-residency form whatever the
     // bound (correct up to 32 keys like V_E32; full 25..32-key sequences would be ~5 % slower on it), a small one V_E32
     const bool dense = (int64_t)num_seq * nhead >= (int64_t)7 * std::max(num_cus(), 1);
-    const int var = v == 0 ? ((top <= 24 || dense) ? V_C32 : V_E32) : v == 1 ? V_C48 : V_80;
+    const int var = v == 0 ? ((top <= 24 || dense) ? V_C32 : V_E32) : (top <= 48 ? V_C48 : V_80);
     const int lds = short_lds_bytes(var, l16);
     auto kern = short_kernel(var);
     hipError_t e = g_attn_marks[var].raise_lds(reinterpret_cast<const void*>(kern), lds);
@@ -516,7 +525,7 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     const int lds = (2 * 32 * kQStride + 32 * (kc + 4) + 96) * 4;
     hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
     if (e != hipSuccess) return e;
-    dim3 grid((len_bound + 31) / 32, nhead, num_seq);
+    dim3 grid(1, nhead, num_seq);                      // one workgroup per (head, slot): it walks its query tiles
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, kc,
                        kAttnShortMax, len_bound);
     return hipGetLastError();
