@@ -210,7 +210,12 @@ def _attn_ref(qkv, offs, lens, dim, nhead):
 
 @pytest.mark.parametrize("lens", [[1], [22] * 15, [70, 3, 35, 64, 33], [5, 0, 9], [129, 31], [480],
                                   # beyond one pass of the 480-key score block: chunks with a running softmax
-                                  [481], [600, 7, 1000], [1537]])
+                                  [481], [600, 7, 1000], [1537],
+                                  # round 5: the short-sequence variant is chosen by length AND workgroup count -- launches that
+                                  # fill the chip take the high-residency forms (<= 24 keys: <64,128,32,8>), 33..48 keys the
+                                  # chunked <64,128,48,4>, 49..80 <32,64,80,3>; 25..32 keys stay on the all-loads-first form
+                                  [11] * 300, [22] * 256, list(range(1, 25)) * 12, [24, 1, 0, 13] * 70, [32, 25, 7] * 100,
+                                  [40, 33, 48, 2] * 8, [48] * 64, [49, 80, 64, 1] * 6, [77] * 40])
 def test_attention(lib, lens):
     dim, nhead = 1936, 8
     g = torch.Generator(device="cuda").manual_seed(sum(lens))
@@ -469,7 +474,12 @@ def test_dsg_layout_flags_bad_indices_and_long_sequences(lib):
 
 
 @pytest.mark.parametrize("lens,bound", [([5, 0, 17, 48, 49, 0, 80, 3], 80), ([30, 81, 0, 200, 12, 64], 230), ([1, 2, 3], 40),
-                                        ([0, 0, 0], 100), ([48, 16], 48)])
+                                        ([0, 0, 0], 100), ([48, 16], 48),
+                                        # round 5: enough slots to fill the chip (the <= 32 class on the high-residency form whatever
+                                        # the bound), the two upper short classes in one launch, the general kernel walking its query
+                                        # tiles in one workgroup per (head, slot)
+                                        ([32, 5, 0, 17, 1, 0, 29, 8] * 40, 176), ([3, 0, 40, 0, 75, 0, 0, 6] * 35, 176),
+                                        ([0, 100, 2, 0, 161, 33] * 45, 176)])
 def test_attention_over_device_side_lengths(lib, lens, bound):
     """every length class in one call, empty slots included; rows of no sequence stay untouched"""
     dim, nhead = 1936, 8
