@@ -510,7 +510,9 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     // pairs / classes ~ 5 tokens): a launch with enough slots to fill the chip takes the high-residency form whatever the
     // bound (correct up to 32 keys like V_E32; full 25..32-key sequences would be ~5 % slower on it), a small one V_E32
     const bool dense = (int64_t)num_seq * nhead >= (int64_t)7 * std::max(num_cus(), 1);
-    const int var = v == 0 ? ((top <= 24 || dense) ? V_C32 : V_E32) : (top <= 48 ? V_C48 : V_80);
+    // (one rule with launch_attention: `short_variant` picks V_C32 for <= 24 keys only when the launch fills the chip --
+    // a small launch is latency-bound and takes V_E32 there as well; `dense` extends V_C32 to bounds of 25..32)
+    const int var = v == 0 ? (dense ? V_C32 : V_E32) : (top <= 48 ? V_C48 : V_80);
     const int lds = short_lds_bytes(var, l16);
     auto kern = short_kernel(var);
     hipError_t e = g_attn_marks[var].raise_lds(reinterpret_cast<const void*>(kern), lds);
@@ -525,7 +527,14 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
     const int lds = (2 * 32 * kQStride + 32 * (kc + 4) + 96) * 4;
     hipError_t e = g_attn_marks_long.raise_lds(reinterpret_cast<const void*>(attention_kernel), lds);
     if (e != hipSuccess) return e;
-    dim3 grid(1, nhead, num_seq);                      // one workgroup per (head, slot): it walks its query tiles
+    // workgroups per (head, slot): each walks its query tiles with stride gridDim.x.  ONE when the launch already fills the
+    // chip (DSG-DETR at 16x12: hundreds of slots, all empty in this class -- an empty workgroup costs nothing, and one per
+    // slot keeps the launch short); a few when there are only a handful of slots with really long sequences, so that their
+    // ceil(L / 32) tiles do not run one after the other on nhead x few workgroups
+    const int tiles = (len_bound + 31) / 32;
+    const int64_t slots = (int64_t)nhead * num_seq;
+    const int gx = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, 2 * (int64_t)std::max(num_cus(), 1) / slots));
+    dim3 grid(gx, nhead, num_seq);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), lds, s, qkv, seq_off, seq_len, out, ldo, dim, hd, scale, kc,
                        kAttnShortMax, len_bound);
     return hipGetLastError();

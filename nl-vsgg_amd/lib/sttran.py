@@ -55,14 +55,21 @@ def _destroy_live_handles():
 atexit.register(_destroy_live_handles)
 
 
-class STTran:
-    """Inference-only STTran (PredCls, and SGDet with `is_wks=True`)."""
+class STTran(torch.nn.Module):
+    """Inference-only STTran (PredCls, and SGDet with `is_wks=True`).
+
+    An `nn.Module` like the reference's class (lib/sttran.py:316), so `isinstance(model, nn.Module)`, `model.eval()`,
+    `.to(device=...)`, `load_state_dict(..., strict=False)`, `state_dict()`, `named_parameters()`, `requires_grad_()` and
+    forward hooks behave the way callers such as lib/ults/init_teacher_model.py:15-29 and tools/test_STTran.py:38-52
+    expect -- but it registers NO torch parameters: the weights live in the native handle, `state_dict()` returns the
+    tensors that were loaded, and `parameters()` is empty (there is nothing to train or to move with `_apply`)."""
 
     _model = nat.MODEL_STTRAN
 
     def __init__(self, mode="sgdet", attention_class_num=None, spatial_class_num=None, contact_class_num=None,
                  obj_classes=None, enc_layer_num=None, dec_layer_num=None, transformer_mode=None, is_wks=True,
                  feat_dim=2048, motifs_path=None, conf=None):
+        super().__init__()
         assert mode in ("sgdet", "sgcls", "predcls")          # lib/sttran.py:329
         if mode == "sgcls":
             raise NotImplementedError("sgcls is not on the hot path (NL-VSGG runs predcls and sgdet only)")
@@ -82,7 +89,7 @@ class STTran:
         self.enc_layer_num = int(enc_layer_num)
         self.dec_layer_num = int(dec_layer_num)
         self.feat_dim = int(feat_dim)
-        self.training = False
+        self.training = False           # inference only: constructed in eval mode (`train(True)` raises)
         self.taps = False               # parity tests: also return stage tensors
         # check_indices (default True = the reference's behaviour): out-of-range `pair_idx` / `labels` raise an
         # IndexError like the torch indexing at lib/sttran.py:381-393 does.  The kernels clamp and set a device flag;
@@ -118,12 +125,16 @@ class STTran:
         self._pending_pairs = 0
         self._device = None
         self._handle = None
-        self._sd = {}
+        self._sd = collections.OrderedDict()
         self._lib = nat.load()          # raises if the HIP extension is missing
 
-    # ---- nn.Module-like surface ------------------------------------------------------------
-    def to(self, device):
-        device = torch.device(device)
+    # ---- the nn.Module surface that differs from the default ------------------------------------------
+    def to(self, *args, **kwargs):
+        """`.to(device)` / `.to(device=gpu_device)` (tools/test_STTran.py:49, lib/ults/init_teacher_model.py:26): selects
+        the MI355X the handle lives on.  dtype arguments are ignored (the path computes in fp32)."""
+        device = torch._C._nn._parse_to(*args, **kwargs)[0]
+        if device is None:
+            return self
         if device.type != "cuda":
             raise RuntimeError("STTran runs on an MI355X only (no CPU path)")
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -135,21 +146,26 @@ class STTran:
     def cuda(self, device=None):
         return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
 
-    def eval(self):
-        self.training = False
-        return self
+    def cpu(self):
+        raise RuntimeError("STTran runs on an MI355X only (no CPU path)")
 
     def train(self, mode=True):
         if mode:
             raise NotImplementedError("inference only (SURVEY.md 2, row 18: training is out of scope)")
-        return self
+        return super().train(False)             # `eval()` is nn.Module's: train(False)
 
-    def parameters(self):
-        return iter(())
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """What was loaded, under the reference's keys (`load_state_dict` keeps the caller's tensors; the device copies
+        belong to the native handle)."""
+        out = collections.OrderedDict() if destination is None else destination
+        for k, v in self._sd.items():
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            out[prefix + k] = t if keep_vars else t.detach()
+        return out
 
-    def load_state_dict(self, state_dict, strict=False):
+    def load_state_dict(self, state_dict, strict=False, assign=False):
         """`model.load_state_dict(ckpt['state_dict'], strict=False)` (tools/test_STTran.py:51-52)."""
-        self._sd = dict(state_dict)
+        self._sd = collections.OrderedDict(state_dict)
         if self._handle is not None:
             self._upload()
         missing, unexpected = self._key_report()
@@ -211,7 +227,7 @@ class STTran:
             self._handle = None
             self._engine_set = None
             self._lanes_set = 1
-            self._drop_inflight()
+            self._drop_inflight(done=True)
             self._pending, self._pending_pairs = [], 0
 
     def __del__(self):
@@ -264,7 +280,7 @@ class STTran:
             nat.check(self._lib, self._handle, self._lib.sttran_set_lanes(self._handle, self._lanes))
             self._lanes_set = self._lanes          # (sttran_set_lanes synchronised the device: nothing is in flight)
             self._next_lane = 0
-            self._drop_inflight()
+            self._drop_inflight(done=True)
 
     @property
     def pipeline_depth(self):
@@ -311,6 +327,10 @@ class STTran:
         if P == 0:
             raise nat.SttranError(3, "entry has no pairs")
         entry["_group"] = None                               # queued: no group yet
+        if self._device is not None:
+            # whatever produced `entry` on the stream current NOW must precede the group's forward, which is forked from the
+            # stream current at flush time (the K-th call, a join, sync_check): remembered per entry, ordered in `_flush`
+            entry["_submit_stream"] = torch.cuda.current_stream(torch.device("cuda", self._device))
         self._pending.append(entry)
         self._pending_pairs += P
         if len(self._pending) >= int(self.coalesce) or 0 < int(self.coalesce_max_pairs) <= self._pending_pairs:
@@ -322,6 +342,10 @@ class STTran:
         if not self._pending:
             return
         group, self._pending, self._pending_pairs = self._pending, [], 0
+        if self._device is not None:
+            cur = torch.cuda.current_stream(torch.device("cuda", self._device))
+            for st in {e.pop("_submit_stream", cur) for e in group} - {cur}:
+                cur.wait_stream(st)                          # entries queued under other streams precede the group forward
         lab = "pred_labels" if self._select else "labels"
         clips = [e if lab == "labels" else dict(e, labels=e[lab]) for e in group]
         packed = pack_clips(clips, copy=False)
@@ -352,17 +376,21 @@ class STTran:
             p0 += np_
             b0 += nb
 
-    def _drop_inflight(self, lane=None):
-        """The tensors kept for a lane's last call are released: its group counts as joined."""
+    def _drop_inflight(self, lane=None, streams=(), done=False):
+        """The tensors kept for a lane's last call are released: its group counts as joined -- on `streams` (the raw
+        handles that were made to wait for the lane), or on every stream when the device was synchronised (`done`)."""
         for l in (list(self._inflight) if lane is None else [lane]):
             rec = self._inflight.pop(l, None)
             if rec is not None:
                 rec[0].joined = True
+                rec[0].joined_on.update(streams)
+                rec[0].done = rec[0].done or done
 
     def join(self, entry=None):
         """Make the current stream wait for the forward that computed `entry` (None: for every lane); returns `entry`.
-        A still-queued entry (`coalesce`) is issued first.  Joining an entry whose group was already joined (another entry
-        of the same coalesced group, or a lane that has been reused since) is free: it never waits for a LATER forward."""
+        A still-queued entry (`coalesce`) is issued first.  Joining an entry whose group was already joined UNDER THIS
+        STREAM (another entry of the same coalesced group, or a lane that has been reused since by a call on this stream)
+        is free; under another stream it waits for the lane (possibly for a later forward on it: never for less)."""
         if entry is None or entry.get("_group", 0) is None:
             self._flush()
         if self._handle is not None:
@@ -373,9 +401,11 @@ class STTran:
                 streams = {rec[0].stream for rec in self._inflight.values()}
             else:
                 g = entry.get("_group")
-                if g is None or g.joined:
+                if g is None or g.done or cur in g.joined_on:
                     return entry
-                lanes, streams = [g.lane], {g.stream}
+                if self._lanes_set <= g.lane:                # (cannot happen: changing the lane count synchronises -> done)
+                    return entry
+                lanes, streams = [g.lane], ({g.stream} if not g.joined else set())
             for lane in lanes:
                 nat.check(self._lib, self._handle, self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(cur)))
                 # torch's caching allocator recycles a block on the stream it was ALLOCATED on (the current stream of the
@@ -383,7 +413,12 @@ class STTran:
                 # before the kept tensors are dropped
                 for st in streams - {cur}:
                     nat.check(self._lib, self._handle, self._lib.sttran_lane_join(self._handle, lane, C.c_void_p(st)))
-            self._drop_inflight(None if entry is None else lanes[0])
+            if entry is None:
+                self._drop_inflight(None, streams | {cur})
+            else:
+                g.joined_on.update(streams | {cur})
+                if not g.joined:
+                    self._drop_inflight(g.lane, streams | {cur})
         return entry
 
     _async = False
@@ -421,14 +456,11 @@ class STTran:
         self._flush()
         stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
         rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
-        self._drop_inflight()                           # sync_check joined every lane and waited
+        self._drop_inflight(done=True)                  # sync_check joined every lane and waited for the device
         if rc == 7:                                     # STTRAN_ERR_INDEX: what torch raises as an IndexError
             msg = self._lib.sttran_last_error(self._handle) or b""
             raise nat.SttranIndexError(rc, msg.decode("utf-8", "replace"))
         nat.check(self._lib, self._handle, rc)
-
-    def __call__(self, entry):
-        return self.forward(entry)
 
     def forward(self, entry):
         """`STTran.forward` (lib/sttran.py:375-411).  `entry` may carry two optional host-side hints
@@ -582,7 +614,7 @@ class STTran:
                 nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(stream)))
                 if prev[0].stream != stream:                 # (see `join`: the allocating stream must have waited as well)
                     nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(prev[0].stream)))
-                self._drop_inflight(lane)
+                self._drop_inflight(lane, {stream, prev[0].stream})
             nat.check(lib, h, lib.sttran_forward_lane(h, lane, C.byref(inp), C.byref(out), C.c_void_p(stream)))
             group = _Group(lane, stream)
             self._inflight[lane] = (group, keep, att, spa, con, dist_out, taps)
@@ -610,12 +642,15 @@ class STTran:
 
 class _Group:
     """One forward issued on a lane: which lane, the stream it was forked from (= the stream torch allocated its tensors
-    on), and whether a consumer stream has been ordered behind it since (then its kept tensors are gone and a `join` of any
-    of its entries is free)."""
-    __slots__ = ("lane", "stream", "joined")
+    on), whether its kept tensors have been released (`joined`: some consumer stream and the allocating stream are ordered
+    behind it) and WHICH streams are ordered behind it (`joined_on`): a `join` of one of its entries is free only under
+    one of those (a join under another stream must still wait for the lane)."""
+    __slots__ = ("lane", "stream", "joined", "joined_on", "done")
 
     def __init__(self, lane, stream):
         self.lane, self.stream, self.joined = lane, stream, False
+        self.joined_on = set()          # raw stream handles that have been made to wait for this forward
+        self.done = False               # the device was synchronised after it: every stream is behind it
 
 
 class PackedClips(dict):

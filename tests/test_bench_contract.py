@@ -9,18 +9,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
-COMPACT_LIMIT = 4096          # the driver keeps the last 8 KB of stdout: the whole line must be in it
+COMPACT_LIMIT = 6000          # the driver keeps the last 8 KB of stdout: the whole line must be in it
 
 
 DOMINANT_KEYS = ("dominant_kernel", "dominant_frac", "dominant_tflops", "dominant_mean_us", "dominant_launches_per_step",
                  "dominant_gflop_per_step")
-CLASS_MS_KEYS = ("ms_gemm", "ms_union_conv", "ms_mask_conv", "ms_attention", "ms_layernorm")
+CLASS_MS_KEYS = ("ms_gemm", "ms_union_conv", "ms_mask_conv", "ms_attention", "ms_layernorm", "ms_index")
+
+
+DRIVER_DICT_CAP = 24          # BENCH_r05.json: `roofline` was emitted with 26 keys, the record kept the first 24
 
 
 def driver_filter(d):
-    """What the driver's `parsed` record keeps of the stdout line (read off BENCH_r04.json): the contract keys; of the
-    dicts among them (`config`, `roofline`, `cpu_baseline`) ONE level of scalars, strings cut at 120 characters, nested
-    dicts / lists dropped; every other top-level key only by name under `extra_keys`."""
+    """What the driver's `parsed` record keeps of the stdout line (read off BENCH_r04.json / BENCH_r05.json): the contract
+    keys; of the dicts among them (`config`, `roofline`, `cpu_baseline`) ONE level of scalars, strings cut at 120
+    characters, nested dicts / lists dropped, AT MOST THE FIRST 24 KEYS (r05 lost `ms_layernorm` / `ms_index` that way);
+    every other top-level key only by name under `extra_keys`."""
     out = {}
     for k in CONTRACT:
         if k not in d:
@@ -28,12 +32,13 @@ def driver_filter(d):
         v = d[k]
         if isinstance(v, dict):
             v = {kk: (vv[:120] if isinstance(vv, str) else vv) for kk, vv in v.items() if not isinstance(vv, (dict, list))}
+            v = dict(list(v.items())[:DRIVER_DICT_CAP])
         out[k] = v
     out["extra_keys"] = sorted(k for k in d if k not in CONTRACT)
     return out
 
 
-def _check_compact(d, dominant=True, driver_record=False):
+def _check_compact(d, dominant=True, class_keys=CLASS_MS_KEYS):
     for k in CONTRACT:
         assert k in d, k
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -44,11 +49,11 @@ def _check_compact(d, dominant=True, driver_record=False):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.0 < r["frac"] < 1.0 and r["peak"] == 157.3
-    # nothing nested under the two dicts the driver flattens: a nested value would be dropped from its record
-    for blk in ("roofline", "cpu_baseline"):
+    # nothing nested under the dicts the driver flattens: a nested value would be dropped from its record
+    for blk in ("config", "roofline", "cpu_baseline"):
         assert not any(isinstance(v, (dict, list)) for v in d[blk].values()), blk
     if dominant:
-        for k in DOMINANT_KEYS + CLASS_MS_KEYS:
+        for k in DOMINANT_KEYS + tuple(class_keys):
             assert k in r, k
         assert "gemm" in r["dominant_kernel"]
         assert r["dominant_tflops"] > 0 and 0.0 < r["dominant_frac"] < 1.0 and r["dominant_launches_per_step"] >= 1
@@ -75,9 +80,13 @@ def _check_compact(d, dominant=True, driver_record=False):
     assert no_tables(d)
 
 
+R5_KEPT = CLASS_MS_KEYS[:4]    # round 5's lines put 26 keys under `roofline`: the driver's 24-key cap drops the last two
+
+
 def test_committed_bench_line_has_the_contract_fields():
     """the newest committed default line (profiles/*bench_default_with_cpu.json = stdout of `python bench.py` on the GPU box)
-    is ONE compact line under the driver's capture size, and its detail file carries the tables"""
+    is ONE compact line under the driver's capture size, survives the driver's filter (scalars, 120 characters, 24 keys per
+    dict) with every roofline / scaling scalar intact, and its detail file carries the tables"""
     lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("bench_default_with_cpu.json")
                    and not f.startswith(("r1_", "r2_", "r3_")))
     if not lines:
@@ -86,36 +95,49 @@ def test_committed_bench_line_has_the_contract_fields():
     raw = open(os.path.join(ROOT, "profiles", lines[-1])).read()
     assert len(raw.strip().splitlines()) == 1 and len(raw.strip()) < COMPACT_LIMIT
     d = json.loads(raw)
-    flat = not lines[-1].startswith("r4_")                  # round 4's lines carry the nested roofline.dominant{} form
+    rnd = lines[-1][:2]
+    flat = rnd != "r4"                                      # round 4's lines carry the nested roofline.dominant{} form
     if not flat:
         d["roofline"] = {k: v for k, v in d["roofline"].items() if not isinstance(v, dict)}
     _check_compact(d, dominant=flat)
-    _check_compact(driver_filter(d), dominant=flat)         # ... and survives what the driver keeps of it
+    # ... and survives what the driver keeps of it (round 5's lines: known to lose the last two ms_* keys to the cap)
+    _check_compact(driver_filter(d), dominant=flat, class_keys=R5_KEPT if rnd == "r5" else CLASS_MS_KEYS)
     assert d["n_gpus"] == 1 and d["one_clip_per_pass"]["value"] > 0 and d["workloads"]["64x36"]["value"] > 0
     assert d["config"]["layout_cache"].startswith("miss") and d["pcie_inclusive_overlapped"]["value"] > 0
+    if rnd not in ("r4", "r5"):
+        for blk in ("config", "roofline", "cpu_baseline"):
+            assert len(d[blk]) <= 22, (blk, len(d[blk]))    # two keys of slack under the driver's cap
+        f = driver_filter(d)
+        # the N = 1 reference points a SCALE reader divides the N > 1 lines' 64x36 figures by
+        assert f["config"]["scale_reference_64x36_frames_per_s"] == d["workloads"]["64x36"]["value"]
+        assert f["config"]["strong_64x36_frames_per_s"] == d["strong_scaling"]["64x36_x64"]["value"]
+        assert d["one_clip_coalesced"]["value"] > d["one_clip_per_pass"]["value"] > d["one_clip_per_pass"]["serial"] > 0
+        c = f["cpu_baseline"]
+        assert c["impl"] in ("numpy", "torch") and c["numpy_value"] > 0 and c["torch_value"] > 0
+        assert abs(c["value"] - max(c["numpy_value"], c["torch_value"])) < 0.02 * c["value"]
+        assert d["workloads"]["16x12_bf16x3"]["value"] > 0 and d["workloads"]["64x36_bf16x3"]["value"] > 0
     det = json.load(open(os.path.join(ROOT, "profiles", lines[-1].replace("bench_default_with_cpu", "bench_default_detail"))))
     r = det["roofline"]
     assert r["by_kernel"] and r["by_shape"] and all(k in r["by_kernel"][0] for k in ("kernel", "launches_per_step", "gflop_per_step", "mean_us"))
     assert det["value"] == d["value"] and det["workloads"]["64x36"]["config"]["frames_per_clip"] == 64
 
 
-def test_compact_line_stays_under_the_driver_capture():
-    """bench.compact_line on a synthetic worst case (8 ranks, every optional block present, long error strings): one JSON
-    line, scalars only, < 4 KB -- round 3's 26 KB line was cut by the driver's 8 KB capture and could not be parsed"""
-    import sys
-    sys.path.insert(0, ROOT)
-    import bench
+def _worst_case(n_gpus):
     blk = {"value": 123456.789012, "ms_per_step": 29.123456789, "roofline": {"frac": 0.123456789}, "cpu_baseline": {"value": 81.123456},
-           "one_clip_per_pass": {"value": 15000.123456}, "allgather_ms": 0.123456789, "max_abs_diff_vs_fp32_engine": 1.6093254089355469e-06}
+           "one_clip_per_pass": {"value": 15000.123456, "serial": {"value": 14000.5}}, "one_clip_coalesced": {"value": 31000.123456},
+           "allgather_ms": 0.123456789, "max_abs_diff_vs_fp32_engine": 1.6093254089355469e-06,
+           "one_rank_alone": {"value": 10345.123, "ms_per_step": 24.7123}, "config": {"frames_per_clip": 64}}
     ss = {"value": 90413.123456, "seconds": 0.60123456, "clips": 1737, "frames": 54371, "ranks": 8, "busy_max_s": 0.123456789,
           "eval_max_s": 0.0123456789, "eval_s_rank0": 0.0123456789, "lpt_imbalance": 1.0123456789, "busy_imbalance": 1.0123456789,
-          "gather_verified": True, "recall_with_constraint": {"10": 0.1, "20": 0.1689, "50": 0.2}, "per_rank": [{"rank": i} for i in range(8)]}
-    d = {"metric": "frames/sec (PredCls inference)", "value": 2048 / (25.6123456789 * 1e-3), "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+          "gather_verified": True, "recall_with_constraint": {"10": 0.1, "20": 0.1689, "50": 0.2}, "per_rank": [{"rank": i} for i in range(8)],
+          "rank0_alone": {"value": 10413.123456, "seconds": 0.4}}
+    d = {"metric": "frames/sec (PredCls inference)", "value": n_gpus * 1024 / (25.6123456789 * 1e-3), "unit": "frames/s", "n_gpus": n_gpus,
+         "steps": 20, "warmup": 5,
          "ms_per_step": 25.6123456789, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-         "config": {"workload": "x" * 300, "clips_per_step": 4, "frames_per_clip": 64, "boxes_per_frame": 36, "pairs_per_step": 8960,
+         "config": {"workload": "x" * 300, "clips_per_step": 64, "frames_per_clip": 16, "boxes_per_frame": 12, "pairs_per_step": 11264,
                     "hip_graph": False, "layout_cache": "miss every step: " + "y" * 200, "batch": "z" * 200, "sharding": "w" * 200},
-         "repeats": [80000.123456, 80001.123456, 79999.123456], "ranks_seen": 8, "distinct_devices": 8,
-         "devices": [{"rank": i, "pci_bus_id": "0000:c5:00.0", "uuid": "GPU-" + "a" * 32} for i in range(8)],
+         "repeats": [80000.123456, 80001.123456, 79999.123456], "ranks_seen": n_gpus, "distinct_devices": n_gpus,
+         "devices": [{"rank": i, "pci_bus_id": "0000:c5:00.0", "uuid": "GPU-" + "a" * 32} for i in range(n_gpus)],
          "roofline": {"bound": "mfma", "achieved": 141.04287222812908, "peak": 157.3, "unit": "TFLOP/s", "frac": 141.04287222812908 / 157.3,
                       "traffic": 1698316052.7472527, "traffic_source": "profiles/r4_z_pmc_traffic_64x36.json", "traffic_measured_in_run": False,
                       "algorithmic_bytes_per_launch": 431937565.09090906, "launches_per_step": 22.0, "avg_launch_us": 1100.2403279834173,
@@ -126,33 +148,73 @@ def test_compact_line_stays_under_the_driver_capture():
                       "per_class_ms_per_step": {"gemm": 24.205123, "union_conv": 4.264123, "mask_conv": 0.667123, "attention": 0.541123,
                                                 "layernorm": 0.233123, "index": 0.018123},
                       "by_kernel": [{"kernel": "k" * 80}] * 12, "by_shape": [{"kernel": "k" * 80}] * 21},
-         "cpu_baseline": {"value": 81.32498323163517, "unit": "frames/s", "cores": 8, "host_cores": 256, "kind": "port", "sample": "s" * 400},
-         "one_clip_per_pass": {"value": 15808.9123, "ms_per_step": 1.0121123}, "same_batch": {"value": 34000.0123, "ms_per_step": 29.9123},
+         "cpu_baseline": {"value": 181.32498323163517, "unit": "frames/s", "cores": 64, "host_cores": 256, "kind": "port", "sample": "s" * 400,
+                          "impl": "torch", "numpy_value": 81.3249, "numpy_cores": 8, "torch_value": 181.32498323163517, "torch_cores": 64,
+                          "torch_value_8_threads": 100.123456, "torch_value_64_threads": 181.32498, "torch_value_all_threads": 150.5,
+                          "host_physical_cores": 128},
+         "one_clip_per_pass": {"value": 20808.9123, "ms_per_step": 0.7121123, "lanes": 3, "serial": {"value": 15808.9, "ms_per_step": 1.01}},
+         "one_clip_coalesced": {"value": 32808.9123, "ms_per_step": 0.4921123, "lanes": 3, "coalesce": 16, "no_hints": {"value": 31000.1},
+                                "result_latency_ms": 23.456789},
+         "same_batch": {"value": 34000.0123, "ms_per_step": 29.9123},
          "pcie_inclusive_overlapped": {"value": 12000.123, "ms_per_step": 80.0123, "h2d_gb_per_s": 55.0123},
-         "one_rank_alone": {"value": 10345.123, "ms_per_step": 24.7123}, "allgather_ms": 0.0823456, "allgather_bytes_per_rank": 931840,
+         "one_rank_alone": {"value": 34345.123, "ms_per_step": 29.7123}, "allgather_ms": 0.0823456, "allgather_bytes_per_rank": 931840,
          "batch_sweep": [{"clips_per_step": 1, "value": 15808.9}, {"clips_per_step": 16, "value": 31803.8}, {"clips_per_step": 64, "value": 34269.6}],
          "reference_arithmetic": {"frac_of_fp32_mfma_peak": 0.9756123},
-         "workloads": {"64x36": blk, "16x12": blk, "ag_split_shaped": ss, "16x12_bf16x3": blk, "dsgdetr_16x12": {"error": "e" * 500}},
+         "workloads": {"64x36": blk, "ag_split_shaped": ss, "16x12_bf16x3": blk, "64x36_bf16x3": blk, "dsgdetr_16x12": {"error": "e" * 500}},
          "strong_scaling": {"64x36_x64": ss, "ag_split_shaped": ss}}
-    line = bench.compact_line(d)
-    assert "\n" not in line and len(line) < COMPACT_LIMIT, len(line)
-    c = json.loads(line)
-    _check_compact(c)
-    # the driver's own record of this line (scalars one level below the contract dicts) still carries the dominant kernel
-    f = driver_filter(c)
-    _check_compact(f)
-    assert f["roofline"]["dominant_kernel"] == "gemm16_kernel<Tile16<128,176>,EpiLinear>" and f["roofline"]["ms_mask_conv"] > 0
-    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
-    assert c["strong_scaling"]["ag_split_shaped"]["eval_s_rank0"] > 0 and c["workloads"]["64x36"]["value"] > 0
+    return d
+
+
+def test_compact_line_stays_under_the_driver_capture():
+    """bench.compact_line on a synthetic worst case (8 ranks, every optional block present, long error strings): one JSON
+    line, scalars only, < 4 KB -- round 3's 26 KB line was cut by the driver's 8 KB capture and could not be parsed -- and at
+    most 22 keys under each dict the driver's record flattens (its cap is 24: round 5's 26-key roofline lost two)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from benchlib import legs_scaling
+    for n in (1, 8):
+        d = _worst_case(n)
+        d["scaling_scalars"] = legs_scaling.scaling_scalars(d, n)
+        line = bench.compact_line(d)
+        assert "\n" not in line and len(line) < COMPACT_LIMIT, len(line)
+        c = json.loads(line)
+        d["config"]["clips_per_step"], d["config"]["frames_per_clip"] = 64, 16
+        _check_compact(c)
+        for blk in ("config", "roofline", "cpu_baseline"):
+            assert len(c[blk]) <= 22, (blk, len(c[blk]))
+        # the driver's own record of this line (scalars one level below the contract dicts, 24 keys each) loses nothing
+        f = driver_filter(c)
+        _check_compact(f)
+        for blk in ("config", "roofline", "cpu_baseline"):
+            assert f[blk].keys() == c[blk].keys(), blk
+        assert f["roofline"]["dominant_kernel"] == "gemm16_kernel<Tile16<128,176>,EpiLinear>" and f["roofline"]["ms_index"] > 0
+        assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+        assert c["strong_scaling"]["ag_split_shaped"]["eval_s_rank0"] > 0 and c["workloads"]["64x36"]["value"] > 0
+        assert f["cpu_baseline"]["impl"] == "torch" and f["cpu_baseline"]["numpy_value"] > 0
+        cfg = f["config"]
+        if n == 1:
+            assert cfg["scale_reference_64x36_frames_per_s"] == round(123456.789012, 1) and cfg["strong_64x36_frames_per_s"] > 0
+        else:
+            # a SCALE reader's ratios, on like-for-like numbers, inside the record itself
+            assert abs(cfg["weak_scaling_efficiency"] - d["value"] / (8 * 34345.123)) < 1e-3
+            assert abs(cfg["speedup_vs_one_rank"] - d["value"] / 34345.123) < 1e-3
+            assert abs(cfg["scale_64x36_speedup_vs_one_rank"] - 123456.789012 / 10345.123) < 1e-3
+            assert cfg["strong_64x36_speedup_basis"] == round(10413.123456, 1)
+            assert abs(cfg["strong_64x36_speedup"] - 90413.123456 / 10413.123456) < 1e-3
+            assert cfg["ranks_seen"] == 8 and cfg["distinct_devices"] == 8 and cfg["allgather_ms"] > 0
 
 
 def test_bench_accepts_the_driver_flags():
-    src = open(os.path.join(ROOT, "bench.py")).read()
+    import glob
+    main = open(os.path.join(ROOT, "bench.py")).read()
+    src = main + "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "benchlib", "*.py"))))
     for flag in ("--gpus", "--steps", "--warmup"):
-        assert re.search(rf'add_argument\("{flag}"', src), flag
+        assert re.search(rf'add_argument\("{flag}"', main), flag
     assert 'all_reduce(t, op=self.dist.ReduceOp.MAX)' in src           # max over ranks
     assert "launch_ranks(args.gpus" in src and "os.exec" not in src     # --gpus N without a launcher: fresh children, never exec
-    assert src.count("env.barrier(gatherer)") >= 2                      # both sides of the timed region
+    assert src.count("env.barrier(w.gatherer)") >= 2                    # both sides of the timed region
+    assert len(main.splitlines()) < 350                                 # the driver file stays a driver (VERDICT r5 weak 11)
     assert "PredictionGatherer" in src                                  # the tested gather is the timed gather
 
 
@@ -174,7 +236,18 @@ def test_newest_driver_bench_line_has_the_contract_fields():
     # BENCH_r04.json: bench.py nested the dominant kernel's row as roofline.dominant{} and the driver's record keeps scalars
     # only, so that record has no dominant row; since round 5 the row is flat `dominant_*` scalars
     # and every later record must carry it
-    _check_compact(d, dominant=os.path.basename(files[-1]) > "BENCH_r04.json")
+    # BENCH_r05.json: 26 keys were emitted under `roofline` and the record keeps 24 -- `ms_layernorm` / `ms_index` are gone
+    # (VERDICT r5 weak 1); since round 6 the line keeps every flattened dict at <= 22 keys and every later record must
+    # carry all of them, plus the scaling scalars inside `config`
+    name = os.path.basename(files[-1])
+    _check_compact(d, dominant=name > "BENCH_r04.json", class_keys=R5_KEPT if name == "BENCH_r05.json" else CLASS_MS_KEYS)
+    if name > "BENCH_r05.json":
+        for blk in ("config", "roofline", "cpu_baseline"):
+            assert len(d[blk]) <= 22, (blk, len(d[blk]))
+        if d["n_gpus"] == 1:
+            assert d["config"]["scale_reference_64x36_frames_per_s"] > 0
+        else:
+            assert 0 < d["config"]["weak_scaling_efficiency"] < 1.2 and d["config"]["ranks_seen"] == d["n_gpus"]
 
 
 def test_missing_device_leaves_a_parseable_error_line():

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-COMPACT_LIMIT = 4096
+COMPACT_LIMIT = 6000
 
 
 def _run(cmd, extra_env=None, timeout=900):
@@ -46,28 +46,50 @@ def _run(cmd, extra_env=None, timeout=900):
 GLOO_ON_GPU0 = {"BENCH_DIST_BACKEND": "gloo", "BENCH_FORCE_DEVICE": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
 
 
-def _check_two_rank_line(c, d, cps):
-    """c = the compact stdout line, d = the detail object"""
+def _check_ranks_line(c, d, cps, n=2):
+    """c = the compact stdout line, d = the detail object of a `--gpus n` run (all ranks on GPU 0, gloo)"""
     for x in (c, d):
-        assert x["n_gpus"] == 2 and x["steps"] == 3 and x["warmup"] == 1 and x["scaling"] == "weak"
+        assert x["n_gpus"] == n and x["steps"] == 3 and x["warmup"] == 1 and x["scaling"] == "weak"
         assert x["value"] > 0 and x["value"] == x["value"] and x["value"] != float("inf")
-        # N > 1: the headline is the 64x36 clip (BASELINE configs[3]); whole-job frames / max-rank time
-        assert x["config"]["frames_per_clip"] == 64 and x["config"]["boxes_per_frame"] == 36
-        assert abs(x["value"] - 2 * cps * 64 / (x["ms_per_step"] * 1e-3)) < 1e-6 * x["value"]
-        assert x["allgather_ms"] > 0 and x["allgather_bytes_per_rank"] == cps * 2240 * 26 * 4
-        assert x["ranks_seen"] == 2 and x["distinct_devices"] == 1 and x["one_rank_alone"]["value"] > 0
+        # the headline is BASELINE configs[1]'s clip (16x12) at EVERY N (round 6): whole-job frames / max-rank time
+        assert x["config"]["frames_per_clip"] == 16 and x["config"]["boxes_per_frame"] == 12
+        assert abs(x["value"] - n * cps * 16 / (x["ms_per_step"] * 1e-3)) < 1e-6 * x["value"]
+        assert x["allgather_ms"] > 0 and x["allgather_bytes_per_rank"] == cps * 176 * 26 * 4
+        assert x["ranks_seen"] == n and x["distinct_devices"] == 1 and x["one_rank_alone"]["value"] > 0
         assert "rank(s)" in x["config"]["sharding"] and x["config"]["layout_cache"].startswith("miss every step")
     assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"]
     assert len(d["repeats"]) == 2 and min(d["repeats"]) <= d["value"] <= max(d["repeats"])
     assert "scaling_note" in d
     # what RCCL (here: gloo) saw
-    assert [x["rank"] for x in d["devices"]] == [0, 1]
-    assert all(x["device"] == 0 and x["pci_bus_id"] for x in d["devices"])         # both ranks forced onto GPU 0 ...
-    assert d["devices"][0]["pid"] != d["devices"][1]["pid"]                        # ... as two processes
-    w = d["workloads"]["16x12"]                                    # configs[1]'s clip rides along
-    assert w["value"] > 0 and w["config"]["frames_per_clip"] == 16 and w["allgather_ms"] > 0
-    assert c["workloads"]["16x12"]["value"] > 0
-    # strong scaling: fixed clip sets sharded over the two ranks, every rank scores its own clips, tallies all-reduced
+    assert [x["rank"] for x in d["devices"]] == list(range(n))
+    assert all(x["device"] == 0 and x["pci_bus_id"] for x in d["devices"])         # every rank forced onto GPU 0 ...
+    assert len({x["pid"] for x in d["devices"]}) == n                              # ... as n processes
+    w = d["workloads"]["64x36"]                                    # configs[3]'s clip rides along, with its own rank-0-alone basis
+    assert w["value"] > 0 and w["config"]["frames_per_clip"] == 64 and w["allgather_ms"] > 0 and w["one_rank_alone"]["value"] > 0
+    assert c["workloads"]["64x36"]["value"] > 0 and c["workloads"]["64x36"]["one_rank_alone"] > 0
+    # the flat scaling scalars sit inside `config`, where the driver's record keeps them, and are what they say they are
+    cfg = c["config"]
+    assert len(cfg) <= 22 and not any(isinstance(v, (dict, list)) for v in cfg.values())
+    one = d["one_rank_alone"]["value"]
+    assert abs(cfg["one_rank_alone_frames_per_s"] - one) < 0.1
+    assert abs(cfg["weak_scaling_efficiency"] - d["value"] / (n * one)) < 1e-3
+    assert abs(cfg["speedup_vs_one_rank"] - d["value"] / one) < 1e-3
+    assert cfg["ranks_seen"] == n and cfg["distinct_devices"] == 1 and cfg["allgather_ms"] > 0
+    assert abs(cfg["scale_64x36_frames_per_s"] - w["value"]) < 0.1
+    assert abs(cfg["scale_64x36_speedup_vs_one_rank"] - w["value"] / w["one_rank_alone"]["value"]) < 1e-3
+    s64 = d["strong_scaling"]["64x36_x64"]
+    assert abs(cfg["strong_64x36_speedup"] - s64["value"] / s64["rank0_alone"]["value"]) < 1e-3
+    assert abs(cfg["strong_64x36_speedup_basis"] - s64["rank0_alone"]["value"]) < 0.1
+    # n ranks share ONE GPU here, so the job cannot be faster than rank 0 alone by more than overlap gains
+    assert cfg["weak_scaling_efficiency"] < 1.5 / n + 0.5
+    # the merged recall table of the sharded set == the table rank 0 computes alone on the same clips
+    assert s64["recall_equals_rank0_alone"] is True
+    # strong scaling: fixed clip sets sharded over the ranks, every rank scores its own clips, tallies all-reduced
+    return s64
+
+
+def _check_two_rank_line(c, d, cps):
+    _check_ranks_line(c, d, cps, 2)
     for key, clips in (("64x36_x64", 6), ("ag_split_shaped", 40)):
         b = d["strong_scaling"][key]
         assert b["clips"] == clips and b["ranks"] == 2 and b["value"] > 0 and b["lpt_imbalance"] >= 1.0
@@ -101,9 +123,12 @@ def test_launcher_counts_gpus_without_the_runtime():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.visible_gpu_count() == torch.cuda.device_count()
-    src = open(os.path.join(ROOT, "bench.py")).read()
-    body = src[src.index("def launch_ranks("):src.index("def pci_bus_id(")]
-    assert "torch.cuda" not in body
+    # the self-launch parent runs bench.py's module level + benchlib/launch.py and nothing else: neither may load torch
+    body = open(os.path.join(ROOT, "benchlib", "launch.py")).read()
+    assert "torch" not in body.replace("torch.distributed.run", "")
+    top = open(os.path.join(ROOT, "bench.py")).read()
+    top = top[top.index('"""', 10) + 3:top.index("def parse_args")]           # the import block between docstring and first def
+    assert "torch" not in top and "benchlib.common" not in top
 
 
 def test_bench_self_launch_propagates_a_failing_rank():
@@ -133,6 +158,31 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     _check_two_rank_line(c, d, 2)
 
 
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """the 8-GPU shot is the driver's and has never run; this is its dry run -- `bench.py --gpus 8`
+    self-launched, all eight ranks on GPU 0 over gloo: the gatherer / LPT assignment / recall all-reduce / rank-0-alone
+    legs with EIGHT ranks, the record a SCALE reader will get, and the wall clock of the whole job"""
+    import time
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    t0 = time.time()
+    c, d = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline",
+                 "--no-roofline", "--clips-per-step", "2", "--strong-clips", "16", "--ag-clips", "64"], GLOO_ON_GPU0, timeout=600)
+    wall = time.time() - t0
+    assert wall < 300, wall
+    s64 = _check_ranks_line(c, d, 2, n=8)
+    assert c["ranks_seen"] == 8 and c["config"]["ranks_seen"] == 8
+    for key, clips in (("64x36_x64", 16), ("ag_split_shaped", 64)):
+        b = d["strong_scaling"][key]
+        assert b["clips"] == clips and b["ranks"] == 8 and b["gather_verified"] is True
+        assert [x["rank"] for x in b["per_rank"]] == list(range(8)) and sum(x["clips"] for x in b["per_rank"]) == clips
+        assert all(x["gather_mismatch"] == 0 for x in b["per_rank"])
+    assert [x["clips"] for x in s64["per_rank"]] == [2] * 8                  # LPT over identical clips: an even split
+    # merged recall == the 1-rank table of the same fixed set (rank 0 alone, same process, same clips)
+    assert s64["recall_with_constraint"] == s64["rank0_alone"]["recall_with_constraint"]
+
+
 def test_bench_default_line_shape():
     """one rank, reduced step counts: the compact line carries every contract field as scalars (< 4 KB); the detail
     object carries the per-kernel roofline rows and the blocks of the other BASELINE configs measured in the same run"""
@@ -153,14 +203,24 @@ def test_bench_default_line_shape():
     assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port"
     for name in ("64x36", "dsgdetr_16x12", "ag_split_shaped"):
         assert c["workloads"][name]["value"] > 0, name
-    assert c["workloads"]["64x36"]["one_clip_per_pass"] > 0 and c["workloads"]["64x36"]["roofline_frac"] > 0
+    assert c["workloads"]["64x36"]["one_clip_coalesced"] > 0 and c["workloads"]["64x36"]["roofline_frac"] > 0
     rf = c["roofline"]
     assert "gemm16_kernel" in rf["dominant_kernel"] and 0 < rf["dominant_frac"] < 1 and rf["dominant_launches_per_step"] >= 1
     assert not any(isinstance(v, (dict, list)) for v in rf.values())          # flat: what the driver's record keeps
     assert rf["ms_gemm"] > rf["ms_union_conv"] > rf["ms_mask_conv"] > 0 and rf["ms_attention"] > 0 and rf["ms_layernorm"] > 0
-    # the reference's one-clip loop: coalesced on the lanes (value), lanes only, serial -- in that order
-    o = c["one_clip_per_pass"]
-    assert o["coalesce"] == 16 and o["value"] > o["lanes_only"] > o["serial"] > 0 and o["no_hints"] > o["lanes_only"]
+    # the reference's one-clip loop: coalesced on the lanes, lanes only (`one_clip_per_pass.value`, as in rounds 1-4), serial
+    o, oc = c["one_clip_per_pass"], c["one_clip_coalesced"]
+    assert oc["coalesce"] == 16 and oc["value"] > o["value"] > o["serial"] > 0 and oc["no_hints"] > o["value"]
+    assert oc["result_latency_ms"] > 0 and d["one_clip_coalesced"]["pipeline_depth"] == 48
+    # flat under config: what the N > 1 lines' 64x36 figures divide by; both CPU samples flat under cpu_baseline
+    assert c["config"]["scale_reference_64x36_frames_per_s"] == c["workloads"]["64x36"]["value"]
+    assert c["config"]["strong_64x36_frames_per_s"] > 0
+    cb = c["cpu_baseline"]
+    assert cb["numpy_value"] > 0 and cb["torch_value"] > 0 and cb["impl"] in ("numpy", "torch") and cb["cores"] >= 1
+    for blk in ("config", "roofline", "cpu_baseline"):
+        assert len(c[blk]) <= 22, (blk, len(c[blk]))
+    for name in ("16x12_bf16x3", "64x36_bf16x3"):
+        assert c["workloads"][name]["value"] > 0 and c["workloads"][name]["max_abs_diff_vs_fp32_engine"] < 2e-5, name
     # RCCL really ran in this run (a one-rank group in a child process): gather verified, all-gather timed
     st = c["rccl_selftest"]
     assert st["ok"] is True and st["backend"] == "nccl" and st["gather_verified"] is True and st["allgather_ms"] > 0, st
@@ -190,6 +250,7 @@ def test_bench_default_line_shape():
     # --profile-only-batch: nothing but warm-up + timed steps
     p, _ = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--profile-only-batch"])
     assert "roofline" not in p and "workloads" not in p and "one_clip_per_pass" not in p and "cpu_baseline" not in p
+    assert "one_clip_coalesced" not in p
     assert "pcie_inclusive_overlapped" not in p
 
 

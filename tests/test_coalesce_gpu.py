@@ -190,6 +190,70 @@ def test_join_under_another_stream_than_the_forward():
     m.sync_check()
 
 
+def test_join_under_a_second_stream_after_the_lane_was_reused():
+    """a group counts as joined once its lane is reused -- but only on the stream that reuse was issued
+    under.  A later `join(entry)` under ANOTHER stream must still order that stream behind the lane (it used to return at
+    once), and a second join under the same stream is free."""
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("predcls", sd)
+    e = syn.make_entry(41, [11] * 16)
+    want = {k: v.clone() for k, v in m(_cuda_entry(e)).items() if k in OUT_KEYS}
+    torch.cuda.synchronize()
+    m.lanes = 2
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        first = m.forward_async(_cuda_entry(e))
+        g = first["_group"]
+        later = [m.forward_async(_cuda_entry(e)) for _ in range(3)]      # reuses first's lane: first's group is `joined`
+        main_h = torch.cuda.current_stream().cuda_stream
+        assert g.joined and g.joined_on == {main_h} and not g.done
+        with torch.cuda.stream(side):
+            m.join(first)
+            assert side.cuda_stream in g.joined_on                           # the side stream was really made to wait
+            out = {k: first[k].clone() for k in OUT_KEYS}
+            n = len(g.joined_on)
+            m.join(first)                                                    # free now
+            assert len(g.joined_on) == n
+        side.synchronize()
+        assert all(torch.equal(out[k], want[k]) for k in OUT_KEYS), rep
+        for p in later:
+            m.join(p)
+    m.sync_check()
+    assert first["_group"].done is True
+
+
+def test_entries_queued_under_another_stream_precede_the_group_forward():
+    """with `coalesce`, the group's forward is forked from the stream current at FLUSH time; an entry whose
+    inputs were produced on another stream (the one current when it was queued) must still be complete before the group
+    reads it.  The producer here is a long chain of kernels on a side stream that ends by writing the entry's tensors."""
+    sd = syn.make_sttran_state_dict(7)
+    m = _model("predcls", sd)
+    e = syn.make_entry(43, [11] * 16)
+    good = _cuda_entry(e)
+    want = {k: v.clone() for k, v in m(dict(good)).items() if k in OUT_KEYS}
+    torch.cuda.synchronize()
+    m.lanes, m.coalesce = 2, 2
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    for rep in range(4):
+        late = {k: (torch.zeros_like(v) if isinstance(v, torch.Tensor) and v.dtype.is_floating_point and k != "im_idx" else v)
+                for k, v in good.items()}
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            x = big
+            for _ in range(20):                                               # ~ms of work ahead of the writes
+                x = x @ big * 1e-3
+            for k in ("features", "union_feat", "spatial_masks"):
+                late[k].copy_(good[k])
+            first = m.forward_async(late)                                     # queued under `side`
+        second = m.forward_async(dict(good))                                  # the K-th call, under the main stream: flush
+        m.join(first); m.join(second)
+        torch.cuda.synchronize()
+        for p in (first, second):
+            assert all(float((p[k] - want[k]).abs().max()) <= 2e-5 for k in OUT_KEYS), rep
+    m.sync_check()
+
+
 def test_sgdet_without_wks_coalesced():
     """`STTran(mode='sgdet', is_wks=False)`: boxes / pairs are selected per clip at submission (data-dependent sizes), the
     relation transformer then runs once per group"""

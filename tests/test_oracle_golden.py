@@ -96,3 +96,30 @@ def test_dsg_detr_oracle_matches_reference(name, golden_dir):
         np.testing.assert_allclose(st["local_output"], g["local_output"], atol=5e-5, rtol=0)
     else:
         np.testing.assert_allclose(st["local_output"][:4], g["local_output_head"], atol=5e-5, rtol=0)
+
+
+# ---- the second restatement (oracle/sttran_torch.py: plain torch on oneDNN, bench.py's other cpu_baseline sample) -------------
+@pytest.mark.parametrize("name", CASES)
+def test_torch_restatement_matches_reference(name, golden_dir, weights):
+    from oracle import sttran_torch as ort
+    g = np.load(os.path.join(golden_dir, f"sttran_{name}.npz"))
+    mode = "sgdet" if "distribution" in g.files else "predcls"
+    sd = _weights(weights, int(g["weight_seed"]))
+    entry = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode=mode,
+                           im_idx_dtype=np.int64 if mode == "sgdet" else np.float32)
+    out = ort.sttran_forward(entry, sd, mode=mode)
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution") + (("distribution",) if mode == "sgdet" else ()):
+        np.testing.assert_allclose(out[k], g[k], atol=TOL, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["dsgdetr_4x3", "dsgdetr_ragged", "dsgdetr_shuffled_boxes", "dsgdetr_empty_frames"])
+def test_torch_restatement_dsg_detr_matches_reference(name, golden_dir):
+    from oracle import sttran_torch as ort
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    sd = syn.make_dsg_detr_state_dict(int(g["weight_seed"]))
+    entry = syn.make_entry(int(g["entry_seed"]), g["pairs_per_frame"].tolist(), mode="sgdet", im_idx_dtype=np.int64)
+    if "box_shuffle_seed" in g.files:
+        entry = syn.shuffle_boxes(entry, int(g["box_shuffle_seed"]))
+    out = ort.dsg_detr_forward(entry, sd)
+    for k in ("attention_distribution", "spatial_distribution", "contacting_distribution", "distribution"):
+        np.testing.assert_allclose(out[k], g[k], atol=5e-5, rtol=0, err_msg=k)
