@@ -55,6 +55,12 @@ int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */
 int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                            int64_t rows, int64_t dim, void* stream);
+/* First half of the spatial-mask branch in one kernel (lib/sttran.py:337-341): Conv2d(2, 128, 7, stride 2, padding 3) ->
+ * ReLU -> BatchNorm2d(128, eval) -> MaxPool2d(3, 2, 1).  masks [P,2,27,27] (or, mask_off != NULL: pair p's masks start at
+ * masks + mask_off[p]); w0p = conv.0.weight packed [128][13 tap groups][2 channels][4 taps], tap 49 = (conv.0.bias, 0);
+ * scale / shift = the folded eval-mode BatchNorm; c2 [P,7,7,128] channel-last.  All device pointers. */
+int sttran_debug_mask_conv1_pool(const float* masks, const int64_t* mask_off, const float* w0p, const float* scale,
+                                 const float* shift, float* c2, int32_t P, void* stream);
 /* Multi-head attention core on packed qkv [tokens, 3*dim] over sequences given by
  * (seq_off, seq_len) device arrays; out [tokens, dim].  nn.MultiheadAttention semantics
  * (q scaled by 1/sqrt(dim/nhead), softmax over the keys of the same sequence). */

@@ -1,0 +1,213 @@
+// api_debug.hip -- sttran_debug_* (include/sttran_hip_debug.h): kernel-level test hooks and experiment switches.  NOT part of
+// the drop-in boundary.
+#include "api_internal.h"
+
+using namespace sttran;
+using namespace sttran_host;
+
+extern "C" {
+
+// ---- kernel-level test hooks -------------------------------------------------------------------
+int sttran_debug_gemm(const float* A, const int32_t* a_rowidx, const float* Wt, const float* bias,
+                      const float* residual, float* C, int64_t M, int64_t N, int64_t K, int32_t relu,
+                      int32_t tile_cfg, int32_t split_k, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3)) return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmPlan plan = plan_gemm(M, N, K, tile_cfg, split_k);
+  static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess ||
+                hipMemset(slab, 0, gemm_slab_bytes()) != hipSuccess))
+    return STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  // arbitrary caller tensors: the select path (B_KMAJOR); with K % 32 == 0 there is no K tail, so the select-free
+  // product path (B_KMAJOR_PAD) is equally valid and is what gets measured
+  hipError_t err = gemm_linear(s, GemmOperand{A, K, a_rowidx}, GemmOperand{Wt, K, nullptr}, (int)M, (int)N, (int)K,
+                               e, plan, slab, K % 32 == 0 ? 1 : 0);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+                             const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                             int32_t relu, int32_t tile_cfg, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < pad32(K) || ldw < pad32(K) || (lda & 3) || (ldw & 3))
+    return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmPlan plan = plan_gemm(M, N, K, tile_cfg, 0);
+  static float* slab = nullptr;   // test hook only: one park buffer for the life of the process
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess ||
+                hipMemset(slab, 0, gemm_slab_bytes()) != hipSuccess))
+    return STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  // a gathered operand's span (GemmOperand::span) is what the forward knows from its buffers; a test hook reads the index
+  // back (one synchronisation) so that the 16x16x4 tiles can be exercised with gathered rows
+  int64_t span = 0;
+  if (a_rowidx) {
+    std::vector<int32_t> idx((size_t)M);
+    if (hipMemcpyAsync(idx.data(), a_rowidx, (size_t)M * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+      return STTRAN_ERR_HIP;
+    for (int32_t v : idx) { if (v < 0) return STTRAN_ERR_INVALID; span = std::max<int64_t>(span, (int64_t)v + 1); }
+  }
+  hipError_t err = gemm_linear(s, GemmOperand{A, lda, a_rowidx, 0, nullptr, span}, GemmOperand{Wt, ldw, nullptr}, (int)M, (int)N,
+                               (int)K, e, plan, slab, 1);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+                         const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                         int32_t relu, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < pad32(K) || ldw < K || (lda & 3)) return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static float* slab = nullptr;
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess)) return STTRAN_ERR_HIP;
+  // weight planes, cached for the last W pointer / shape (test hook: one matrix at a time)
+  static void* planes = nullptr;
+  static size_t planes_bytes = 0;
+  static const float* cached_w = nullptr;
+  static int64_t cached_n = 0, cached_k = 0;
+  const int64_t ldp = pad32(K);
+  const size_t need = (size_t)3 * N * ldp * 2 + 256;
+  if (need > planes_bytes) {
+    if (planes) hipFree(planes);
+    if (hipMalloc(&planes, need) != hipSuccess) { planes = nullptr; planes_bytes = 0; return STTRAN_ERR_HIP; }
+    planes_bytes = need;
+    cached_w = nullptr;
+  }
+  // the planes are re-made on every call (a freed W may come back at the same address with other contents) unless the
+  // caller vouches for W staying put: STTRAN_X3_CACHE_PLANES=1 (tools/gemm_bench.py times the GEMM alone that way)
+  static const bool cache_ok = exp_env("STTRAN_X3_CACHE_PLANES") && atoi(exp_env("STTRAN_X3_CACHE_PLANES")) != 0;   // experiment builds only
+  if (!cache_ok || cached_w != Wt || cached_n != N || cached_k != K) {
+    if (split_planes(s, Wt, ldw, (int)N, (int)K, planes, ldp) != hipSuccess) return STTRAN_ERR_HIP;
+    cached_w = Wt; cached_n = N; cached_k = K;
+  }
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  hipError_t err = gemm_linear_x3(s, GemmOperand{A, lda, a_rowidx}, planes, ldp, N * ldp, (int)M, (int)N, (int)K, e, slab);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+// Test allocator: `bytes` of device memory whose end is the end of the mapping -- the page behind it is reserved address
+// space with nothing mapped, so a kernel that reads or writes past a caller's buffer faults instead of silently touching
+// a neighbour (tests/test_guarded_buffers_gpu.py).  HIP virtual-memory API; STTRAN_ERR_HIP where the driver has none.
+namespace {
+struct GuardedAlloc { void* base; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+}
+int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie) {
+  if (!ptr || !cookie || bytes == 0) return STTRAN_ERR_INVALID;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return STTRAN_ERR_HIP;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return STTRAN_ERR_HIP;
+  auto* g = new GuardedAlloc{};
+  g->mapped = (bytes + gran - 1) / gran * gran;
+  g->reserved = g->mapped + gran;                                  // one unmapped granule behind the data
+  bool ok = hipMemAddressReserve(&g->base, g->reserved, gran, nullptr, 0) == hipSuccess;
+  bool created = false, mapped = false;
+  if (ok) ok = created = hipMemCreate(&g->handle, g->mapped, &prop, 0) == hipSuccess;
+  if (ok) ok = mapped = hipMemMap(g->base, g->mapped, 0, g->handle, 0) == hipSuccess;
+  if (ok) {
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = hipMemSetAccess(g->base, g->mapped, &acc, 1) == hipSuccess;
+  }
+  if (!ok) {
+    if (mapped) hipMemUnmap(g->base, g->mapped);
+    if (created) hipMemRelease(g->handle);
+    if (g->base) hipMemAddressFree(g->base, g->reserved);
+    delete g;
+    (void)hipGetLastError();
+    return STTRAN_ERR_HIP;
+  }
+  const size_t span = (bytes + 15) & ~size_t(15);                  // 16-byte aligned start, <= 15 bytes of slack at the end
+  *ptr = static_cast<char*>(g->base) + (g->mapped - span);
+  *cookie = g;
+  return STTRAN_OK;
+}
+int sttran_debug_guarded_free(void* cookie) {
+  if (!cookie) return STTRAN_ERR_INVALID;
+  auto* g = static_cast<GuardedAlloc*>(cookie);
+  hipDeviceSynchronize();
+  hipMemUnmap(g->base, g->mapped);
+  hipMemRelease(g->handle);
+  hipMemAddressFree(g->base, g->reserved);
+  delete g;
+  return STTRAN_OK;
+}
+
+int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return -STTRAN_ERR_INVALID;
+  return plan_gemm(M, N, K, 0, 0).tile;
+}
+
+int sttran_debug_mfma_peak(int32_t iters, double* tflops) {
+  if (iters <= 0 || !tflops) return STTRAN_ERR_INVALID;
+  float* out = nullptr;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&out), 256) != hipSuccess) return STTRAN_ERR_HIP;
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  launch_mfma_peak(nullptr, out, iters, ncu);            // warm-up
+  hipEventRecord(a, nullptr);
+  launch_mfma_peak(nullptr, out, iters, ncu);
+  hipEventRecord(b, nullptr);
+  hipEventSynchronize(b);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a); hipEventDestroy(b); hipFree(out);
+  // per block: 4 waves x iters x 4 MFMAs x (32*32*2*2 flops)
+  *tflops = (double)ncu * 4.0 * iters * 4.0 * 4096.0 / (ms * 1e-3) / 1e12;
+  return STTRAN_OK;
+}
+
+int sttran_debug_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                           int64_t dim, void* stream) {
+  if (!x || !gamma || !beta || !y) return STTRAN_ERR_INVALID;
+  return launch_layernorm(reinterpret_cast<hipStream_t>(stream), x, dim, gamma, beta, y, dim, rows, (int)dim) == hipSuccess
+             ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_mask_conv1_pool(const float* masks, const int64_t* mask_off, const float* w0p, const float* scale,
+                                 const float* shift, float* c2, int32_t P, void* stream) {
+  if (!masks || !w0p || !scale || !shift || !c2 || P < 0) return STTRAN_ERR_INVALID;
+  return launch_mask_conv1_pool(reinterpret_cast<hipStream_t>(stream), masks, mask_off, w0p, nullptr, scale, shift, c2, P) ==
+                 hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_attention(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
+                           int32_t max_len, float* out, int64_t tokens, int32_t dim, int32_t nhead, void* stream) {
+  (void)tokens;
+  if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
+  return launch_attention(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, nullptr, num_seq, max_len, out, dim,
+                          dim, nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+// test hook: the DSG-DETR class-sequence tables exactly as the forward builds them on the device, and (len_bound > 0)
+// the attention over sequences whose lengths only the device knows
+int sttran_debug_dsg_layout(const int64_t* pair_idx, const int64_t* labels, int64_t num_boxes, const int32_t* clip_start,
+                            int32_t num_clips, int32_t num_classes, int64_t num_pairs, int32_t pe_rows, int32_t* dec_off,
+                            int32_t* dec_len, int32_t* dec_src, int32_t* need, int32_t* out_src, int32_t* scratch4p,
+                            int32_t* err_flag, void* stream) {
+  if (!pair_idx || !labels || !clip_start || !dec_off || !dec_len || !dec_src || !need || !out_src || !scratch4p || !err_flag)
+    return STTRAN_ERR_INVALID;
+  return launch_dsg_layout(reinterpret_cast<hipStream_t>(stream), pair_idx, labels, (int)num_boxes, clip_start, num_clips,
+                           num_classes, (int)num_pairs, pe_rows, 1 << 30, dec_off, dec_len, dec_src, need, out_src, scratch4p,
+                           err_flag, (int)std::min<int64_t>(num_pairs, 6144)) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+int sttran_debug_attention_classes(const float* qkv, const int32_t* seq_off, const int32_t* seq_len, int32_t num_seq,
+                                   int32_t len_bound, float* out, int32_t dim, int32_t nhead, void* stream) {
+  if (!qkv || !seq_off || !seq_len || !out || nhead <= 0 || dim % nhead) return STTRAN_ERR_INVALID;
+  return launch_attention_classes(reinterpret_cast<hipStream_t>(stream), qkv, seq_off, seq_len, num_seq, len_bound, out, dim,
+                                  dim, nhead) == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+
+}  // extern "C"

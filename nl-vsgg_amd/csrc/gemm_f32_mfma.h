@@ -65,7 +65,7 @@ struct GemmOperand {
 // staging: rows past M / N are loaded from a clamped row and never stored by the epilogue, the K tail multiplies
 // whatever A holds by B's zeros.  This removes the select (4 v_cndmask per 16 bytes) from the main loop; it is the
 // product path: weights are stored with zero-padded rows, and every activation buffer has a row stride of ceil32(K)
-// floats whose pad columns are zeroed once and never written (sttran_api.hip::ensure_workspace), so the K tail is
+// floats whose pad columns are zeroed once and never written (api_layout.hip::ensure_workspace), so the K tail is
 // 0 x 0 whatever earlier calls left in the workspace.  B_KMAJOR (with the select) takes any operands.
 // B_UNION_FLAT: the 1x1 convolution union_func1 (lib/sttran.py:336,386) on the NCHW union_feat tensor U[P][K][49] read
 // in place: GEMM column = pair * 49 + hw, running straight over the pair borders (N = 49 P exactly: no padded columns,

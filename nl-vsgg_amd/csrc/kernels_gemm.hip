@@ -123,7 +123,7 @@ hipError_t gemm_linear(hipStream_t s, const GemmOperand& A, const GemmOperand& B
 hipError_t gemm_heads(hipStream_t s, const GemmOperand& A, const GemmOperand& B, int M, int N, int K,
                       const EpiHeads& epi, GemmPlan plan, float* slab) {
   if (M <= 0 || N <= 0) return hipSuccess;
-  // N = 26: only the 64x64 tile makes sense (sttran_api.hip forces it); padded operands
+  // N = 26: only the 64x64 tile makes sense (api_forward.hip forces it); padded operands
   return launch_tile<GemmTile<64, 64, 2, 2, B_KMAJOR_PAD>, EpiScalar4<EpiHeads>>(s, TILE_64x64, A, B, M, N, K, slab, EpiScalar4<EpiHeads>{epi});
 }
 #ifdef STTRAN_GEMM_EXPERIMENT   // round 2's 32x32x2 forms of the two convolutions: A/B runs only (STTRAN_CONV_ENGINE=32x32)

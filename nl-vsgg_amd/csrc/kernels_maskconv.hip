@@ -11,8 +11,15 @@
 //     K is ordered (tap, channel-of-the-lane-half), i.e. in every v_mfma_f32_32x32x2_f32 the lower 32
 //     lanes carry input channel 0 and the upper 32 lanes input channel 1 of the same tap;
 //   * the B operand is never materialised (no im2col): the pair's two 27x27 masks sit zero-padded to 33x33
-//     in LDS, and B[k][n] is a single LDS read at  lane_base(n, half) + tap_offset, where the tap offset
-//     is a compile-time immediate -- no address arithmetic and no bounds tests in the loop.
+//     in LDS, and B[k][n] is a single LDS read at  lane_base + column_block_offset + tap_offset, where both offsets
+//     are compile-time immediates -- no address arithmetic and no bounds tests in the loop;
+//   * LDS layout of a padded plane (round 6; rounds 1-5 kept it row-major and read it at stride 2 -- every operand read
+//     a 2-way bank conflict, SQ_LDS_BANK_CONFLICT = 63 % of the kernel's LDS cycles together with the pooling reads):
+//     the stride-2 convolution reads padded (2 oy + ky, 2 ox + kx), so the plane is split into its four (row parity,
+//     column parity) sub-planes [17][17]; tap (ky, kx) reads sub-plane (ky & 1, kx & 1) at (oy + ky / 2, ox + kx / 2) --
+//     neighbouring output columns are neighbouring floats.  A 32-column MFMA block holds TWO output rows (28 positions,
+//     4 padding columns: 7 blocks = 14 rows = the same 224 columns as before): its lanes read 14 + 14 consecutive floats
+//     17 apart (+ 4 padding lanes on the 4 banks left over) = 32 distinct banks of `ds_read_b32`'s 32.
 //
 // What bounds it (round 5, s_memtime traces + PMC): an fp32 MFMA executes on the SIMD's vector ALUs -- beside a wave that
 // issues v_mfma_f32_32x32x2_f32 back to back the other wave of the SIMD gets almost no vector instruction through (an
@@ -47,21 +54,30 @@ extern "C" int sttran_debug_mc_fine(unsigned long long* out) {
 namespace sttran {
 namespace {
 
-constexpr int kMcW = 33;                     // 27 + 2 * 3 padding
-constexpr int kMcPlane = kMcW * kMcW;        // 1089 floats per padded input channel
+constexpr int kMcSubW = 17;                  // a parity sub-plane of the 33 x 33 padded plane (27 + 2 * 3): [17][17]
+constexpr int kMcSub = kMcSubW * kMcSubW;    // 289 floats
+constexpr int kMcPlane = 4 * kMcSub;         // 1156 floats per padded input channel: sub-planes (row parity, column parity)
 constexpr int kMcMask = 2 * kMcPlane;        // one pair
 constexpr int kMcGroups = 13;                // 52 taps (49 real) in groups of 4 (the register layout of the weights)
 constexpr int kMcUnits = 25;                 // executed K: 25 units of two taps (tap 49 has zero weights; 50, 51 are skipped)
 constexpr int kMcPoolCh = 8;                 // channels pooled per round and wave
 constexpr int kMcPoolW = 15;                 // a pooled channel's 14 x 14 conv map with a -inf row above and column left of it
-constexpr int kMcPoolPlane = kMcPoolW * kMcPoolW;   // 225 floats (odd: channels start on different LDS banks)
+constexpr int kMcPoolPlane = kMcPoolW * kMcPoolW;   // 225 floats
+// where the pooled channel c of a round starts in the wave's pooling buffer: 225 c + 12 for every two channels.  The pooling
+// reads of a 32-lane group are 4 channels (0..3 or 4..7) x 7 window columns at stride 2; with these starts (0, 1, 14, 15 and
+// 16, 17, 30, 31 mod 32) the four channels' seven addresses fall on 28 distinct banks (a plain 225 c gave starts 0, 1, 2, 3
+// and channel-fastest lanes: up to 4-way conflicts on each of the 63 reads of a round)
+__host__ __device__ constexpr int pool_base(int c) { return c * kMcPoolPlane + 12 * (c >> 1); }
+constexpr int kMcPool = pool_base(kMcPoolCh - 1) + kMcPoolPlane;   // 1836 floats per wave
 constexpr int kMcWaves = 4;
-constexpr int kMcOutRow = 40;                // a wave's pooled result waits in LDS as [49 positions][32 channels], rows 40 floats apart
-constexpr int kMcOut = 49 * kMcOutRow;       // (8 q + ch + 8 (pos % 4): the 32 lanes of a write hit 32 banks)
-constexpr int kMcLdsFloats = 2 * kMcMask + kMcWaves * (kMcPoolCh * kMcPoolPlane + kMcOut) + 3 * 128;
+constexpr int kMcOutRow = 36;                // a wave's pooled result waits in LDS as [49 positions][32 channels], rows 36 floats apart
+constexpr int kMcOut = 49 * kMcOutRow;       // (36 px + ch: the 28 lanes of a write hit 28 banks)
+constexpr int kMcLdsFloats = 2 * kMcMask + kMcWaves * (kMcPool + kMcOut) + 3 * 128;
 
-// float offset of tap t < 49 inside a padded plane
-__host__ __device__ constexpr int tap_offset(int t) { return (t / 7) * kMcW + (t % 7); }
+// float offset of tap t < 49 = (ky, kx) from the lane's base (oy, ox) of sub-plane (0, 0)
+__host__ __device__ constexpr int tap_offset(int t) {
+  return (((t / 7) & 1) * 2 + ((t % 7) & 1)) * kMcSub + ((t / 7) >> 1) * kMcSubW + ((t % 7) >> 1);
+}
 
 __global__ void __launch_bounds__(256, 2)
 mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restrict__ mask_off, const float* __restrict__ w0p,
@@ -71,53 +87,46 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: scalar registers
   const int fr = lane & 31, fh = lane >> 5;
-  float* pool = lds + 2 * kMcMask + wave * (kMcPoolCh * kMcPoolPlane);  // wave-private [8][15][15], row 0 / column 0 = -inf
-  float* outb = lds + 2 * kMcMask + kMcWaves * kMcPoolCh * kMcPoolPlane + wave * kMcOut;   // wave-private [49][40]
-  float* par = lds + 2 * kMcMask + kMcWaves * (kMcPoolCh * kMcPoolPlane + kMcOut);            // bias | scale | shift, [3][128]
+  float* pool = lds + 2 * kMcMask + wave * kMcPool;                      // wave-private 8 x [15][15], row 0 / column 0 = -inf
+  float* outb = lds + 2 * kMcMask + kMcWaves * kMcPool + wave * kMcOut;   // wave-private [49][36]
+  float* par = lds + 2 * kMcMask + kMcWaves * (kMcPool + kMcOut);         // bias | scale | shift, [3][128]
 
   // weights of this lane: channel 32*wave + fr, k = (group, half, e)  (w0p is [128][104] in that order)
   f32x4 a[kMcGroups];
 #pragma unroll
   for (int g = 0; g < kMcGroups; ++g)
     a[g] = *reinterpret_cast<const f32x4*>(w0p + (wave * 32 + fr) * (kMcGroups * 8) + g * 8 + fh * 4);
-  // Per-lane maps, kept as a few packed registers and expanded where they are used (the accumulators, the weights and the
-  // masks in flight leave ~40 registers for everything else):
-  //  * conv column n = 32 j + fr is output position (oy, ox) = (n / 14, n % 14).  The seven quotients oy <= 13 ride in `oyq`,
-  //    four bits each; columns >= 196 (j = 6, fr >= 4) are padding and take oy = 0.
-  //    B base of the column (its receptive field starts at padded row 2 oy, column 2 ox of the lane-half's channel):
-  //        fh * 1089 + 66 oy + 2 ox = (fh * 1089 + 2 fr) + 64 j + 38 oy
-  //    where its activation goes in the wave's pooling plane ((oy + 1, ox + 1) of the 15 x 15 bordered map):
-  //        (fr + 16) + 32 j + oy
-  //  * pooling: output o = lane + 64 i of a round's 49 x 8 block, channel fastest (the result is stored channel-last,
-  //    [pair][7][7][128], so that the 3x3 convolution behind it gathers 4 channels per load): channel o % 8 = lane % 8,
-  //    position pos = lane / 8 + 8 i = 7 py + px.  The 3x3 / stride-2 / padding-1 window of (py, px) covers conv rows
-  //    2py-1 .. 2py+1 and columns 2px-1 .. 2px+1; with the -inf border row / column in front of the map every window is nine
-  //    unconditional reads at base + {0,1,2} + {0,15,30} (MaxPool2d pads with -inf, lib/sttran.py:341), base =
-  //        ch * 225 + 30 py + 2 px = (ch * 225 + 2 (lane / 8)) + 16 i + 16 py      (py <= 6: three bits each in `pyq`)
-  //    The pooled value goes to the wave's LDS result block at (lane / 8) * 40 + lane % 8 + 320 i + 8 q; when the four rounds
-  //    are done the block leaves as WHOLE 128-byte lines (a position's 32 channels of this wave), 16 bytes per lane: round
-  //    1-4's dword stores wrote a line in four 32-byte pieces, one per round, and the first piece of every line stalled the
-  //    wave for the line's allocation (s_memtime trace: the first round's stores took 16 k cycles, the others 1.7 k).
-  unsigned oyq = 0, pyq = 0;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int n = 32 * j + fr;
-    oyq |= (unsigned)((n < 196 ? n : 0) / 14) << (4 * j);
-    pyq |= (unsigned)(min((lane >> 3) + 8 * j, 48) / 7) << (3 * j);
-  }
-  const int lb0 = fh * kMcPlane + 2 * fr, pw0 = fr + kMcPoolW + 1;
-  const int pb0 = (lane & 7) * kMcPoolPlane + 2 * (lane >> 3), ob0 = (lane >> 3) * kMcOutRow + (lane & 7);
+  // Per-lane maps: ONE base register each, everything else is an immediate.
+  //  * conv column (block j, lane fr): output position (oy, ox) = (2 j + hi, fr - 14 hi), hi = fr >= 14; fr >= 28 is padding.
+  //    B base of the column in its lane-half's channel plane:  fh * 1156 + 17 oy + ox = lb0 + 34 j;  the padding lanes read
+  //    (and discard) the floats on the four banks the 28 real lanes leave free: lb0 = 14, 15, 16, 31 past the block's start.
+  //    Where its activation goes in the wave's pooling plane ((oy + 1, ox + 1) of the 15 x 15 bordered map): pw0 + 30 j.
+  //  * pooling: one pooled ROW per iteration (py = i): lane = 32 g + l, l < 28 -> channel 4 g + l / 7, column px = l % 7.
+  //    The 3x3 / stride-2 / padding-1 window of (py, px) covers conv rows 2py-1 .. 2py+1 and columns 2px-1 .. 2px+1; with
+  //    the -inf border row / column in front of the map every window is nine unconditional reads at pb0 + 30 i + {0,1,2} +
+  //    {0,15,30} (MaxPool2d pads with -inf, lib/sttran.py:341).  Lanes l >= 28 read lane 0's window (same addresses:
+  //    broadcast) and store nothing.  The pooled value goes to the wave's LDS result block at ob0 + 252 i + 8 q; when the
+  //    four rounds are done the block leaves as WHOLE 128-byte lines (a position's 32 channels of this wave), 16 bytes per
+  //    lane: round 1-4's dword stores wrote a line in four 32-byte pieces, one per round, and the first piece of every
+  //    line stalled the wave for the line's allocation (s_memtime trace: the first round's stores took 16 k cycles, the
+  //    others 1.7 k).
+  const int hi = fr >= 14 ? 1 : 0, oxl = fr - 14 * hi;
+  const int lb0 = fh * kMcPlane + (fr < 28 ? kMcSubW * hi + oxl : (fr == 31 ? 31 : fr - 14));
+  const int pw0 = (kMcPoolW + 1) + kMcPoolW * hi + oxl + fh * pool_base(4);
+  const int pl = lane & 31, pact = pl < 28, pch = pact ? pl / 7 : 0, ppx = pact ? pl % 7 : 0;
+  const int pb0 = (lane >> 5) * pool_base(4) + pch * kMcPoolPlane + 12 * (pch >> 1) + 2 * ppx;     // pool_base(4 g + pch) + 2 px
+  const int ob0 = ppx * kMcOutRow + 4 * (lane >> 5) + pch;
   for (int i = lane; i < kMcPoolCh * (2 * kMcPoolW - 1); i += 64) {    // the border of the wave's eight planes, once
     const int ch = i / (2 * kMcPoolW - 1), r = i - ch * (2 * kMcPoolW - 1);
-    pool[ch * kMcPoolPlane + (r < kMcPoolW ? r : (r - kMcPoolW + 1) * kMcPoolW)] = -INFINITY;
+    pool[pool_base(ch) + (r < kMcPoolW ? r : (r - kMcPoolW + 1) * kMcPoolW)] = -INFINITY;
   }
   for (int i = tid; i < 2 * kMcMask; i += 256) lds[i] = 0.f;           // the padding of both mask buffers stays zero for good
   for (int i = tid; i < 128; i += 256) { par[128 + i] = scale[i]; par[256 + i] = shift[i]; }
   __syncthreads();
 
-  auto mask_slot = [](int i) {                                         // element i of [2][27][27] -> padded offset
-    const int ci = i / 729, r = i - ci * 729, y = r / 27, x = r - y * 27;
-    return ci * kMcPlane + (y + 3) * kMcW + (x + 3);
+  auto mask_slot = [](int i) {                                         // element i of [2][27][27] -> its parity sub-plane
+    const int ci = i / 729, r = i - ci * 729, y = r / 27 + 3, x = r - (y - 3) * 27 + 3;
+    return ci * kMcPlane + ((y & 1) * 2 + (x & 1)) * kMcSub + (y >> 1) * kMcSubW + (x >> 1);
   };
   // pair p's masks: a batch of clips may leave them in per-clip tensors (mask_off, written by pair_prep_kernel)
   auto mask_base = [&](int q) { return masks + (mask_off ? mask_off[q] : (int64_t)q * 1458); };
@@ -153,29 +162,27 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
     for (int j = 0; j < 7; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    // K loop in units of two taps (one ds_read2_b32 per column block and unit: both tap offsets are immediates), software-
-    // pipelined by hand: the 7 reads of unit u + 1 are issued between the 14 MFMAs of unit u (one read per two MFMAs), so a
-    // wave alone keeps the matrix pipe fed -- hipcc's own schedule of the plain loop nest read, waited for lgkmcnt(0) and
-    // issued two or three MFMAs, 180 times per pair.
-    unsigned oy_ = oyq;                       // opaque: expanded HERE, per pair -- hoisted out of the pair loop the seven
-    asm volatile("" : "+v"(oy_));             // addresses are spilled (and reloaded behind vmcnt(0) waits)
-    int lb[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) lb[j] = lb0 + 64 * j + 38 * (int)((oy_ >> (4 * j)) & 15u);
+    // K loop in units of two taps, software-pipelined by hand: the 14 reads of unit u + 1 are issued between the 14 MFMAs
+    // of unit u (one read per MFMA; every address is the lane's base + an immediate), so a wave alone keeps the matrix pipe
+    // fed -- hipcc's own schedule of the plain loop nest read, waited for lgkmcnt(0) and issued two or three MFMAs, 180
+    // times per pair.
+    int lb = lb0;                             // opaque: the address register is rebuilt HERE, per pair -- hoisted out of
+    asm volatile("" : "+v"(lb));              // the pair loop hipcc materialises the 7 x 50 addresses and spills them
+    const float* mb = mbuf + lb;
     float bq[2][7][2];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      bq[0][j][0] = mbuf[lb[j] + tap_offset(0)];
-      bq[0][j][1] = mbuf[lb[j] + tap_offset(1)];
+      bq[0][j][0] = mb[2 * kMcSubW * j + tap_offset(0)];
+      bq[0][j][1] = mb[2 * kMcSubW * j + tap_offset(1)];
     }
 #pragma unroll
     for (int u = 0; u < kMcUnits; ++u) {
       if (u + 1 < kMcUnits) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-          bq[(u + 1) & 1][j][0] = mbuf[lb[j] + tap_offset(2 * u + 2)];
+          bq[(u + 1) & 1][j][0] = mb[2 * kMcSubW * j + tap_offset(2 * u + 2)];
           // tap 49 is the bias tap: its weights are (bias[channel], 0) for the two lane halves, its operand is 1
-          bq[(u + 1) & 1][j][1] = 2 * u + 3 < 49 ? mbuf[lb[j] + tap_offset(2 * u + 3)] : 1.f;
+          bq[(u + 1) & 1][j][1] = 2 * u + 3 < 49 ? mb[2 * kMcSubW * j + tap_offset(2 * u + 3)] : 1.f;
         }
       }
 #pragma unroll
@@ -185,8 +192,8 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(2 * u + tt) >> 2][(2 * u + tt) & 3], bq[u & 1][j][tt], acc[j], 0, 0, 0);
       if (u + 1 < kMcUnits) {
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+        for (int j = 0; j < 14; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
         }
       }
@@ -201,8 +208,8 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
 #endif
     MC_FINE(0);
     float* dst = c2 + (int64_t)p * (49 * 128) + wave * 32;
-    unsigned oy_ = oyq, py_ = pyq;            // opaque, as in conv()
-    asm volatile("" : "+v"(oy_), "+v"(py_));
+    int pw = pw0, pb = pb0, ob = ob0;         // opaque, as in conv(): one base register each, the rest are immediates
+    asm volatile("" : "+v"(pw), "+v"(pb), "+v"(ob));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float cs[4], ct[4];
@@ -212,15 +219,12 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
         cs[r] = par[128 + ch]; ct[r] = par[256 + ch];
       }
       MC_FINE(1 + 5 * q);
+      if (fr < 28) {                          // (columns 28..31 of every block are padding)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int n = 32 * j + fr;
-        if (n < 196) {
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            pool[(r + 4 * fh) * kMcPoolPlane + pw0 + 32 * j + (int)((oy_ >> (4 * j)) & 15u)] =
-                relu_nan(acc[j][4 * q + r]) * cs[r] + ct[r];            // (the bias came in through tap 49)
-        }
+          for (int r = 0; r < 4; ++r)         // channel r + 4 fh of the round: plane pool_base(r) (+ pool_base(4) fh, in pw)
+            pool[pool_base(r) + pw + 2 * kMcPoolW * j] = relu_nan(acc[j][4 * q + r]) * cs[r] + ct[r];   // (bias: tap 49)
       }
       // `pool` is private to this wave and a wave's LDS operations execute in program order: the lanes' writes above are
       // visible to the reads below without a workgroup barrier; the compiler must keep the order
@@ -230,24 +234,21 @@ mask_conv1_pool_kernel(const float* __restrict__ masks, const int64_t* __restric
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       MC_FINE(3 + 5 * q);
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int o = lane + 64 * i;
-        if (o < kMcPoolCh * 49) {
-          const float* s = pool + pb0 + 16 * i + 16 * (int)((py_ >> (3 * i)) & 7u);
-          const float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[kMcPoolW], s4 = s[kMcPoolW + 1], s5 = s[kMcPoolW + 2],
-                      s6 = s[2 * kMcPoolW], s7 = s[2 * kMcPoolW + 1], s8 = s[2 * kMcPoolW + 2];
-          // NaN-propagating maximum of the nine (torch's max_pool2d returns NaN if the window holds one): four v_max3 and
-          // five unordered compares -- not eight compare / select chains
-          // (inline asm: fmaxf() makes hipcc canonicalise every loaded operand with a v_max_f32 x, x first)
-          float m0, m1, m2, m;
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(s0), "v"(s1), "v"(s2));
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(s3), "v"(s4), "v"(s5));
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(s6), "v"(s7), "v"(s8));
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m0), "v"(m1), "v"(m2));
-          const bool un = __builtin_isunordered(s0, s1) | __builtin_isunordered(s2, s3) | __builtin_isunordered(s4, s5) |
-                          __builtin_isunordered(s6, s7) | __builtin_isunordered(s8, s8);
-          outb[ob0 + 8 * kMcOutRow * i + kMcPoolCh * q] = un ? __builtin_nanf("") : m;
-        }
+      for (int i = 0; i < 7; ++i) {           // pooled row py = i of the round's eight channels
+        const float* s = pool + pb + 2 * kMcPoolW * i;
+        const float s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[kMcPoolW], s4 = s[kMcPoolW + 1], s5 = s[kMcPoolW + 2],
+                    s6 = s[2 * kMcPoolW], s7 = s[2 * kMcPoolW + 1], s8 = s[2 * kMcPoolW + 2];
+        // NaN-propagating maximum of the nine (torch's max_pool2d returns NaN if the window holds one): four v_max3 and
+        // five unordered compares -- not eight compare / select chains
+        // (inline asm: fmaxf() makes hipcc canonicalise every loaded operand with a v_max_f32 x, x first)
+        float m0, m1, m2, m;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m0) : "v"(s0), "v"(s1), "v"(s2));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m1) : "v"(s3), "v"(s4), "v"(s5));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m2) : "v"(s6), "v"(s7), "v"(s8));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(m0), "v"(m1), "v"(m2));
+        const bool un = __builtin_isunordered(s0, s1) | __builtin_isunordered(s2, s3) | __builtin_isunordered(s4, s5) |
+                        __builtin_isunordered(s6, s7) | __builtin_isunordered(s8, s8);
+        if (pact) outb[ob + 7 * kMcOutRow * i + kMcPoolCh * q] = un ? __builtin_nanf("") : m;
       }
       MC_FINE(4 + 5 * q);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next round's writes stay behind these reads

@@ -255,7 +255,10 @@ def _evaluator():
 FRAMES4 = [9, 2, 7, 3, 3, 5, 2]          # 7 clips over 4 ranks with costs that leave the ranks 1..3 clips; + rank 3 emptied below
 
 
-def _worker_world4(rank, world, port, q):
+FRAMES8 = [9, 2, 7, 3, 3, 5, 2, 8, 4, 6, 2, 2, 5, 3, 7, 4, 2, 6, 3]     # 19 clips over 8 ranks (7 owners + one rank emptied)
+
+
+def _worker_world4(rank, world, port, q, FRAMES4=FRAMES4):
     import numpy as np
     from nl_vsgg_amd.lib.distributed import all_reduce_recall
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -299,21 +302,24 @@ def _worker_world4(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_world4_unequal_packs_empty_rank_and_merged_recall():
+@pytest.mark.parametrize("world,FRAMES4", [(4, FRAMES4), (8, FRAMES8)])
+def test_world4_unequal_packs_empty_rank_and_merged_recall(world, FRAMES4):
+    """world 4, and world 8 = the rank count of the driver's one SCALE shot (more than 4 ranks of the
+    gatherer / LPT / tally code had never run)"""
     import numpy as np
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_world4, args=(r, 4, port, q)) for r in range(4)]
+    procs = [ctx.Process(target=_worker_world4, args=(r, world, port, q, FRAMES4)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get() for _ in procs], key=lambda r: r[0])
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _, _ in res), res
+    assert len(res) == world and all(ok for _, ok, _, _ in res), res
     npacks = res[0][3]
-    assert npacks[3] == 0 and len(set(npacks[:3])) > 1, npacks           # an empty rank, unequal pack counts elsewhere
+    assert npacks[world - 1] == 0 and len(set(npacks[:world - 1])) > 1, npacks     # an empty rank, unequal pack counts elsewhere
     # the merged table == one evaluator over all clips in one process (the reference's loop), on every rank
     ev = _evaluator()
     for i, f in enumerate(FRAMES4):

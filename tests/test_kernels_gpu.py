@@ -538,3 +538,68 @@ def test_gemm_t16_operand_larger_than_4_gb(lib):
     torch.cuda.synchronize()
     assert torch.equal(C3, C4)                         # same launch geometry: the gathered read changes nothing
     assert (C3 - Cc[probe]).abs().max().item() < 1e-4  # (another M = another stream-K cut of the K sum: close, not identical)
+
+
+# ---- mask_conv1_pool_kernel: Conv2d(2,128,7,s2,p3) -> ReLU -> BN(eval) -> MaxPool2d(3,2,1), one kernel (lib/sttran.py:337-341) ----
+def _pack_w0(w0, b0):
+    """conv.0.weight [128][2][7][7] -> [128][13 groups][2 channels][4 taps]; tap 49 = (bias, 0) (csrc/api_weights.hip)"""
+    w = w0.reshape(128, 2, 49).cpu().numpy()
+    wp = np.zeros((128, 13, 2, 4), np.float32)
+    for t in range(49):
+        wp[:, t // 4, :, t % 4] = w[:, :, t]
+    wp[:, 49 // 4, 0, 49 % 4] = b0.cpu().numpy()
+    return torch.from_numpy(wp.reshape(128, 104)).cuda()
+
+
+@pytest.mark.parametrize("P", [1, 2, 7, 176, 515, 1031])
+def test_mask_conv1_pool_against_torch_fp64(lib, P):
+    """every output position of every channel (the kernel's column -> position map, parity sub-plane layout of the padded
+    masks, pooling windows incl. the -inf border) against F.conv2d / batch_norm / max_pool2d in float64, incl. pair counts
+    that are no multiple of the grid and masks scattered through per-pair offsets (the by-pointer batch form)"""
+    F = torch.nn.functional
+    g = torch.Generator(device="cuda").manual_seed(900 + P)
+    masks = torch.rand(P, 2, 27, 27, device="cuda", generator=g) - 0.5
+    w0 = (torch.rand(128, 2, 7, 7, device="cuda", generator=g) - 0.5) * 0.2
+    b0 = torch.rand(128, device="cuda", generator=g) - 0.5
+    scale = torch.rand(128, device="cuda", generator=g) + 0.5
+    scale[::3] *= -1                                         # a negative BN gain reverses the order inside a pooling window
+    shift = torch.rand(128, device="cuda", generator=g) - 0.5
+    ref = F.conv2d(masks.double(), w0.double(), b0.double(), stride=2, padding=3).clamp_min(0)
+    ref = F.max_pool2d(ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None], 3, 2, 1)
+    ref = ref.permute(0, 2, 3, 1).contiguous()              # channel-last [P,7,7,128]
+    wp = _pack_w0(w0, b0)
+    out = torch.full((P, 7, 7, 128), float("nan"), device="cuda")
+    assert lib.sttran_debug_mask_conv1_pool(_p(masks), None, _p(wp), _p(scale), _p(shift), _p(out), P, None) == 0
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    # the same pairs stored in reverse order with gaps, addressed through mask_off
+    pool = torch.zeros(P * 1500 + 64, device="cuda")
+    off = torch.tensor([(P - 1 - p) * 1500 + 8 for p in range(P)], device="cuda", dtype=torch.int64)
+    for p in range(P):
+        pool[int(off[p]):int(off[p]) + 1458] = masks[p].reshape(-1)
+    out2 = torch.full((P, 7, 7, 128), float("nan"), device="cuda")
+    assert lib.sttran_debug_mask_conv1_pool(_p(pool), _p(off), _p(wp), _p(scale), _p(shift), _p(out2), P, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_mask_conv1_pool_propagates_nan_like_torch(lib):
+    """torch's max_pool2d returns NaN for a window that holds one, ReLU keeps NaN: one poisoned mask element must poison
+    exactly the pooled outputs whose receptive field contains it, in every channel"""
+    F = torch.nn.functional
+    g = torch.Generator(device="cuda").manual_seed(77)
+    masks = torch.rand(3, 2, 27, 27, device="cuda", generator=g) - 0.5
+    masks[1, 1, 13, 5] = float("nan")
+    w0 = (torch.rand(128, 2, 7, 7, device="cuda", generator=g) - 0.5) * 0.2
+    b0 = torch.rand(128, device="cuda", generator=g) - 0.5
+    scale = torch.rand(128, device="cuda", generator=g) + 0.5
+    shift = torch.rand(128, device="cuda", generator=g) - 0.5
+    ref = F.conv2d(masks, w0, b0, stride=2, padding=3)
+    ref = torch.where(torch.isnan(ref), ref, ref.clamp_min(0))
+    ref = F.max_pool2d(ref * scale[None, :, None, None] + shift[None, :, None, None], 3, 2, 1).permute(0, 2, 3, 1)
+    out = torch.zeros(3, 7, 7, 128, device="cuda")
+    assert lib.sttran_debug_mask_conv1_pool(_p(masks), None, _p(_pack_w0(w0, b0)), _p(scale), _p(shift), _p(out), 3, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.isnan(out).any() and not torch.isnan(out[0]).any()
+    ok = ~torch.isnan(ref)
+    assert (out[ok] - ref[ok]).abs().max().item() < 2e-5
