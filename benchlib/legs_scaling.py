@@ -50,6 +50,11 @@ def one_rank_alone(w):
             "note": "rank 0 runs the same per-GPU steps while the other ranks idle; no gather"}
 
 
+def _dist_up():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 class SoloEnv:
     """Rank 0 of an N > 1 job acting as a one-rank job (no collectives): the basis leg of `strong_scaling`."""
     def __init__(self, env):
@@ -170,7 +175,10 @@ def strong_scaling(env, model, name, clip_specs, pack, cost_of):
         stat["eval_s"] += time.perf_counter() - t_e
         if gatherer is not None:
             gatherer.wait_all()
-        table = all_reduce_recall(ev, device=device)           # ONE all-reduce of the (sum, count) tallies
+        # ONE all-reduce of the (sum, count) recall tallies -- over the job's group; a rank acting alone (SoloEnv inside an
+        # N > 1 job: torch.distributed IS initialised there) must not enter a collective the other ranks never join
+        table = all_reduce_recall(ev, device=device) if (env.dist is not None or not _dist_up()) else \
+            ev.summary_from_partial_sums(ev.partial_sums())
         torch.cuda.synchronize()
         if verify and gatherer is not None:
             gatherer.raise_if_overflowed()

@@ -43,6 +43,15 @@ int sttran_debug_gemm_padded(const float* A, int64_t lda, const int32_t* a_rowid
 int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
                          const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
                          int32_t relu, void* stream);
+/* The same product through the second-generation bf16x3 kernel (csrc/gemm_bf16x3_t16.h: v_mfma_f32_16x16x32_bf16 on 128 x 176 /
+ * 128 x 128 tiles, both operands pre-split into fragment-major planes).  N must be a multiple of 176 or 128. */
+int sttran_debug_gemm_emulated_t16(const float* A, int64_t lda, const int32_t* a_rowidx, const float* W, int64_t ldw,
+                         const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                         int32_t relu, void* stream);
+/* tools/x3_bench.py: `iters` back-to-back launches of the 16x16x32 bf16x3 kernel on operands split once (us[0], microseconds
+ * per launch) and of the activation split alone (us[1]).  Device pointers; lda, ldw multiples of 4. */
+int sttran_debug_x3t16_bench(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
+                             float* C, int64_t M, int64_t N, int64_t K, int32_t iters, double* us);
 /* Calibration: fp32-MFMA rate (TFLOP/s) this device sustains on a register-only MFMA loop. */
 int sttran_debug_mfma_peak(int32_t iters, double* tflops);
 /* Test allocator: `bytes` of device memory (16-byte aligned) that END at the end of a mapping; the address range behind

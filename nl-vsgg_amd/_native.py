@@ -135,6 +135,10 @@ SYMBOLS = [
                                            C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     ("sttran_debug_gemm_emulated", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    ("sttran_debug_gemm_emulated_t16", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    ("sttran_debug_x3t16_bench", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_double)]),
     ("sttran_debug_mfma_peak", C.c_int, [C.c_int32, C.POINTER(C.c_double)]),
     ("sttran_debug_plan_tile", C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     ("sttran_debug_guarded_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

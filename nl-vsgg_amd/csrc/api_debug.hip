@@ -88,6 +88,76 @@ int sttran_debug_gemm_emulated(const float* A, int64_t lda, const int32_t* a_row
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
 }
 
+// the same through the second-generation kernel (gemm_bf16x3_t16.h): both operands split into fragment-major planes (the
+// weight on every call: test hook), N must be a multiple of 176 or 128
+int sttran_debug_gemm_emulated_t16(const float* A, int64_t lda, const int32_t* a_rowidx, const float* Wt, int64_t ldw,
+                                   const float* bias, const float* residual, float* C, int64_t M, int64_t N, int64_t K,
+                                   int32_t relu, void* stream) {
+  if (!A || !Wt || !C || M <= 0 || N <= 0 || K <= 0 || (K & 3) || lda < K || ldw < K || (lda & 3) || (ldw & 3)) return STTRAN_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static float* slab = nullptr;
+  if (!slab && (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess)) return STTRAN_ERR_HIP;
+  static void *pa = nullptr, *pb = nullptr;
+  static size_t pa_bytes = 0, pb_bytes = 0;
+  auto grow = [](void*& p, size_t& have, size_t need) {
+    if (need <= have) return true;
+    if (p) hipFree(p);
+    if (hipMalloc(&p, need) != hipSuccess) { p = nullptr; have = 0; return false; }
+    have = need;
+    return true;
+  };
+  if (!grow(pa, pa_bytes, fm_planes_bytes(M, K) + 256) || !grow(pb, pb_bytes, fm_planes_bytes(N, K) + 256)) return STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, relu);
+  e.res = residual; e.ldres = N;
+  if (!x3t16_tile((int)N, e)) return STTRAN_ERR_INVALID;
+  if (split_fm(s, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb) != hipSuccess) return STTRAN_ERR_HIP;
+  if (split_fm(s, A, lda, a_rowidx, nullptr, (int)M, (int)K, pa) != hipSuccess) return STTRAN_ERR_HIP;
+  hipError_t err = gemm_linear_x3t16(s, pa, pb, (int)((N + 15) / 16), (int)M, (int)N, (int)K, e, slab);
+  return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
+}
+
+// tools/x3_bench.py: the 16x16x32 kernel and the activation split timed apart (HIP events, `iters` back-to-back launches
+// each, operands split once up front); us[0] = GEMM, us[1] = split_fm of A
+int sttran_debug_x3t16_bench(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* residual,
+                             float* C, int64_t M, int64_t N, int64_t K, int32_t iters, double* us) {
+  if (!A || !Wt || !C || !us || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return STTRAN_ERR_INVALID;
+  float* slab = nullptr;
+  void *pa = nullptr, *pb = nullptr;
+  hipEvent_t e0, e1;
+  int rc = STTRAN_ERR_HIP;
+  EpiLinear e = epi_plain(C, N, bias, 0);
+  e.res = residual; e.ldres = N;
+  float ms = 0.f;
+  if (hipMalloc(reinterpret_cast<void**>(&slab), gemm_slab_bytes()) != hipSuccess) return rc;
+  if (hipMalloc(&pa, fm_planes_bytes(M, K) + 256) != hipSuccess || hipMalloc(&pb, fm_planes_bytes(N, K) + 256) != hipSuccess) goto out;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  if (!x3t16_tile((int)N, e)) { rc = STTRAN_ERR_INVALID; goto out2; }
+  if (split_fm(nullptr, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb) != hipSuccess) goto out2;
+  if (split_fm(nullptr, A, lda, nullptr, nullptr, (int)M, (int)K, pa) != hipSuccess) goto out2;
+  for (int i = 0; i < 3; ++i)
+    if (gemm_linear_x3t16(nullptr, pa, pb, (int)((N + 15) / 16), (int)M, (int)N, (int)K, e, slab) != hipSuccess) goto out2;
+  hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; ++i) gemm_linear_x3t16(nullptr, pa, pb, (int)((N + 15) / 16), (int)M, (int)N, (int)K, e, slab);
+  hipEventRecord(e1, nullptr);
+  if (hipEventSynchronize(e1) != hipSuccess) goto out2;
+  hipEventElapsedTime(&ms, e0, e1);
+  us[0] = 1e3 * ms / iters;
+  hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; ++i) split_fm(nullptr, A, lda, nullptr, nullptr, (int)M, (int)K, pa);
+  hipEventRecord(e1, nullptr);
+  if (hipEventSynchronize(e1) != hipSuccess) goto out2;
+  hipEventElapsedTime(&ms, e0, e1);
+  us[1] = 1e3 * ms / iters;
+  rc = STTRAN_OK;
+out2:
+  hipEventDestroy(e0); hipEventDestroy(e1);
+out:
+  if (pa) hipFree(pa);
+  if (pb) hipFree(pb);
+  hipFree(slab);
+  return rc;
+}
+
 // Test allocator: `bytes` of device memory whose end is the end of the mapping -- the page behind it is reserved address
 // space with nothing mapped, so a kernel that reads or writes past a caller's buffer faults instead of silently touching
 // a neighbour (tests/test_guarded_buffers_gpu.py).  HIP virtual-memory API; STTRAN_ERR_HIP where the driver has none.

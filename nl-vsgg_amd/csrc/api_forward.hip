@@ -31,6 +31,32 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
   }
   if (h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && (M >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL) &&
       N >= 128 && !force_tile) {
+    // (1) the 16x16x32 tiles on pre-split fragment-major operands (gemm_bf16x3_t16.h): N a multiple of 176 or 128, K <= 4096
+    //     (vr_fc's K = 12 544 operand would need 0.85 GB of planes: it stays on the in-loader split below), one gather table
+    const int t16 = (K <= 4096 && !(A.aux > 0)) ? x3t16_tile(N, epi) : 0;
+    if (t16) {
+      for (auto& kv : h->w) {
+        const Tensor& t = kv.second;
+        if (!t.planes_fm || !t.ld || t.ld != pad32(K)) continue;
+        const int64_t rows = t.shape[0];
+        if (Wt < t.d || Wt >= t.d + rows * t.ld) continue;
+        const int64_t r0 = (Wt - t.d) / t.ld;
+        if ((Wt - t.d) % t.ld || r0 + N > rows || (r0 & 15)) break;
+        const size_t need = fm_planes_bytes(M, K) + 256;
+        if (need > h->L->aplanes.bytes) {
+          HIPCK(hipStreamSynchronize(s));
+          HIPCK(h->L->aplanes.ensure(need + need / 4));
+        }
+        const int kb = (K + 31) / 32;
+        ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
+                     std::string("gemm16x3_kernel<Tile16<") + tile_name(t16) + ">,EpiLinear> + split_fm_kernel", M, N, K);
+        HIPCK(split_fm(s, A.ptr, A.ld, A.rowidx, A.rowoff, M, K, h->L->aplanes.p));
+        HIPCK(gemm_linear_x3t16(s, h->L->aplanes.p, reinterpret_cast<const uint16_t*>(t.planes_fm) + (r0 / 16) * kb * 1536,
+                                (int)((rows + 15) / 16 - r0 / 16), M, N, K, epi, h->L->slab.as<float>()));
+        return STTRAN_OK;
+      }
+    }
+    // (2) round 2's kernel (gemm_bf16x3.h): activations split by the A loader
     if (Wt == h->fc_w && h->fc_planes) {               // the grouped subj_fc | obj_fc launch (a derived tensor, not in h->w)
       const int64_t ldf = pad32(K);
       ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
@@ -163,6 +189,9 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       const size_t bytes = (size_t)3 * t.shape[0] * t.ld * 2 + 256;
       if (!t.planes) HIPCK(hipMalloc(&t.planes, bytes));
       HIPCK(split_planes(s, t.d, t.ld, (int)t.shape[0], (int)t.shape[1], t.planes, t.ld));
+      // ... and fragment-major (gemm_bf16x3_t16.h): [ceil(rows / 16)][ceil(cols / 32)][3][512], zero beyond rows / cols
+      if (!t.planes_fm) HIPCK(hipMalloc(&t.planes_fm, fm_planes_bytes(t.shape[0], t.shape[1]) + 256));
+      HIPCK(split_fm(s, t.d, t.ld, nullptr, nullptr, (int)t.shape[0], (int)t.shape[1], t.planes_fm));
     }
     {   // the 1x1 union conv's weight [256, feat_dim, 1, 1] is a [256, feat_dim] GEMM operand too (feat_dim % 32 == 0)
       Tensor& t = h->w["union_func1.weight"];

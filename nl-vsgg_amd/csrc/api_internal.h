@@ -34,6 +34,7 @@ struct Tensor {
   float* d = nullptr;
   void* d_guard = nullptr;      // STTRAN_GUARD_WORKSPACE: cookie of the guarded allocation behind `d`
   void* planes = nullptr;  // bf16x3 engine: [3][rows][ld] bf16 planes of a GEMM weight (made on demand)
+  void* planes_fm = nullptr;   // ... and its fragment-major planes (gemm_bf16x3_t16.h), for the launches the 16x16x32 tiles serve
   std::vector<int64_t> shape;
   size_t n = 0;
   int64_t ld = 0;          // != 0: a [rows, cols] GEMM weight stored with this row stride (cols zero-padded to pad32)
@@ -108,6 +109,7 @@ struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
 struct Lane {
   int64_t capP = 0, capB = 0;
   sttran_host::DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
+  sttran_host::DevBuf aplanes;  // bf16x3 engine: fragment-major planes of the activation operand of the GEMM in flight
   sttran_host::DevBuf dsg;                   // DSG-DETR: class-sequence tables built on the device (launch_dsg_layout)
   sttran_host::DevBuf ctab, poff;            // chunk table of the call's inputs (kernels.h ChunkTable); per-pair element offsets [4 P] int64
   std::vector<int64_t> ctab_host;   // what ctab holds (re-uploaded only when a call's pointers / sizes differ)

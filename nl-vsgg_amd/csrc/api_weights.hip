@@ -156,6 +156,7 @@ void sttran_destroy(SttranHandle* h) {
   for (auto& kv : h->w) {
     weight_free(kv.second);
     if (kv.second.planes) hipFree(kv.second.planes);
+    if (kv.second.planes_fm) hipFree(kv.second.planes_fm);
   }
   if (h->w4_planes) hipFree(h->w4_planes);
   if (h->fc_planes) hipFree(h->fc_planes);

@@ -107,7 +107,7 @@ __device__ __forceinline__ void split3(const f32x4& v, bf16x4& h, bf16x4& m, bf1
 }
 
 // One-off: split a [rows, cols] fp32 matrix (row stride ld) into three zero-padded bf16 planes [3][rows][ldp].
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 split_planes_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols, __bf16* __restrict__ planes, int64_t ldp) {
   const int r = blockIdx.x;
   for (int c = threadIdx.x; c < (int)ldp; c += 256) {

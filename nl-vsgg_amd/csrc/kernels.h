@@ -84,6 +84,17 @@ hipError_t launch_mask_conv2_x3(hipStream_t s, const void* planes, const float* 
 hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const int64_t* u_off, const void* planes, const float* bias,
                                 float* V, int P, int K, float* slab);
 
+// second generation of the same engine (gemm_bf16x3_t16.h): both operands as FRAGMENT-MAJOR bf16 planes
+// [row block 16][K block 32][plane 3][512] -- fm_planes_bytes(rows, K) bytes; split_fm makes them from fp32 rows (optionally
+// gathered: rowoff = 64-bit element offsets, else rowidx), zero beyond M rows / K columns
+size_t fm_planes_bytes(int64_t rows, int64_t K);
+hipError_t split_fm(hipStream_t s, const float* src, int64_t ld, const int32_t* rowidx, const int64_t* rowoff, int M, int K,
+                    void* planes);
+int x3t16_tile(int N, const EpiLinear& epi);          // TILE_128x176 / TILE_T128x128, or 0 = shape / epilogue not served
+// b_planes = the weight's planes at its first needed row block; b_row_blocks = row blocks available from there
+hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                             const EpiLinear& epi, float* slab);
+
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // Where the inputs of one call live: n chunks, chunk c = the tensors of one clip as the caller passed them (SttranInputs'
 // per-clip pointer tables) or ONE chunk = the whole contiguous batch.  All members are DEVICE arrays: the two prefix

@@ -1,0 +1,78 @@
+// kernels_gemm_x3t16.hip -- the bf16x3 engine on the 128 x 176 / 128 x 128 tiles (gemm_bf16x3_t16.h): instantiation and launch
+#include "gemm_bf16x3_t16.h"
+#include "gemm_launch.h"
+
+namespace sttran {
+
+size_t fm_planes_bytes(int64_t rows, int64_t K) {
+  return (size_t)((rows + 15) / 16) * (size_t)((K + 31) / 32) * kFmBlock3 * sizeof(__bf16);
+}
+
+hipError_t split_fm(hipStream_t s, const float* src, int64_t ld, const int32_t* rowidx, const int64_t* rowoff, int M, int K,
+                    void* planes) {
+  if (M <= 0 || K <= 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) || (ld & 3) || (reinterpret_cast<uintptr_t>(planes) & 15)) return hipErrorInvalidValue;
+  const int kb = (K + 31) / 32;
+  const int64_t blocks = (int64_t)((M + 15) / 16) * kb;
+  hipLaunchKernelGGL(split_fm_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, src, ld, rowidx, rowoff, M, K, kb, blocks,
+                     reinterpret_cast<__bf16*>(planes));
+  return hipGetLastError();
+}
+
+template <class T, int TILE_ID>
+static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes& B, int M, int N, int K, const EpiLinear& epi,
+                               float* slab) {
+  using Epi = EpiLinearV;
+  static DeviceMarks marks;
+  auto kern = gemm16x3_kernel<T, Epi>;
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles = tm * tn;
+  const int ksteps = (K + kBK - 1) / kBK;
+  const SkPlan sp = sk_plan(TILE_ID, tiles, ksteps);
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
+  bool split = false;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  const int half = T::GROUP_N;
+  const Epi e{epi};
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
+                     base, rem, half, slab, e);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess || !split) return err;
+  hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps, sp.g_sk,
+                     base, rem, tiles - sp.tiles_sk, half, slab, e);
+  return hipGetLastError();
+}
+
+static bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the tile this engine would run [M,N,K] on: TILE_128x176, TILE_T128x128, or 0 = not served (N is no multiple of 176 or 128,
+// or the epilogue's operands do not allow 16-byte accesses: the caller falls back)
+int x3t16_tile(int N, const EpiLinear& epi) {
+  const bool vec = al16p(epi.C) && (epi.ldc & 3) == 0 && al16p(epi.bias) && al16p(epi.rowbias) && (epi.rb_ld & 3) == 0 &&
+                   (epi.rb_cols & 3) == 0 && al16p(epi.scale) && al16p(epi.shift) && al16p(epi.res) && (epi.ldres & 3) == 0;
+  if (!vec) return 0;
+  if (N % 176 == 0) return TILE_128x176;
+  if (N % 128 == 0) return TILE_T128x128;
+  return 0;
+}
+
+// a_planes: fragment-major planes of A [M, K] (split_fm); b_planes: of the weight, at its first needed ROW BLOCK (16 rows each)
+hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                             const EpiLinear& epi, float* slab) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int tile = x3t16_tile(N, epi);
+  if (!tile || !al16p(a_planes) || !al16p(b_planes) || b_row_blocks * 16 < N) return hipErrorInvalidValue;
+  const int kb = (K + 31) / 32;
+  const FmPlanes A{reinterpret_cast<const __bf16*>(a_planes), kb, (M + 15) / 16};
+  const FmPlanes B{reinterpret_cast<const __bf16*>(b_planes), kb, b_row_blocks};
+  if (tile == TILE_128x176) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, epi, slab);
+  return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, epi, slab);
+}
+
+}  // namespace sttran

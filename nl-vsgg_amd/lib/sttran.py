@@ -114,6 +114,7 @@ class STTran(torch.nn.Module):
         self._lanes_set = 1
         self._next_lane = 0
         self._inflight = {}             # lane -> (_Group, tensors) of its last un-joined call (see _run)
+        self._epoch = 0                 # bumped by every device synchronisation (sync_check, set_lanes): older groups are done
         # coalescing (no reference counterpart; the reference's loop is one clip per call, tools/test_STTran.py:75-88 with
         # dataloader/wk_action_genome.py:622-627): `model.coalesce = K` makes `forward_async(entry)` only QUEUE the entry;
         # every K queued entries (or `coalesce_max_pairs` queued pairs, or a `join` / `sync_check` / classic `forward`
@@ -378,13 +379,15 @@ class STTran(torch.nn.Module):
 
     def _drop_inflight(self, lane=None, streams=(), done=False):
         """The tensors kept for a lane's last call are released: its group counts as joined -- on `streams` (the raw
-        handles that were made to wait for the lane), or on every stream when the device was synchronised (`done`)."""
+        handles that were made to wait for the lane).  `done`: the device was synchronised -- EVERY group issued so far
+        (also the ones whose lane has been reused since) is behind every stream: the epoch moves on."""
         for l in (list(self._inflight) if lane is None else [lane]):
             rec = self._inflight.pop(l, None)
             if rec is not None:
                 rec[0].joined = True
                 rec[0].joined_on.update(streams)
-                rec[0].done = rec[0].done or done
+        if done:
+            self._epoch += 1
 
     def join(self, entry=None):
         """Make the current stream wait for the forward that computed `entry` (None: for every lane); returns `entry`.
@@ -401,7 +404,7 @@ class STTran(torch.nn.Module):
                 streams = {rec[0].stream for rec in self._inflight.values()}
             else:
                 g = entry.get("_group")
-                if g is None or g.done or cur in g.joined_on:
+                if g is None or g.epoch < self._epoch or cur in g.joined_on:
                     return entry
                 if self._lanes_set <= g.lane:                # (cannot happen: changing the lane count synchronises -> done)
                     return entry
@@ -616,7 +619,7 @@ class STTran(torch.nn.Module):
                     nat.check(lib, h, lib.sttran_lane_join(h, lane, C.c_void_p(prev[0].stream)))
                 self._drop_inflight(lane, {stream, prev[0].stream})
             nat.check(lib, h, lib.sttran_forward_lane(h, lane, C.byref(inp), C.byref(out), C.c_void_p(stream)))
-            group = _Group(lane, stream)
+            group = _Group(lane, stream, self._epoch)
             self._inflight[lane] = (group, keep, att, spa, con, dist_out, taps)
             entry["_lane"], entry["_group"] = lane, group
         else:
@@ -645,12 +648,12 @@ class _Group:
     on), whether its kept tensors have been released (`joined`: some consumer stream and the allocating stream are ordered
     behind it) and WHICH streams are ordered behind it (`joined_on`): a `join` of one of its entries is free only under
     one of those (a join under another stream must still wait for the lane)."""
-    __slots__ = ("lane", "stream", "joined", "joined_on", "done")
+    __slots__ = ("lane", "stream", "joined", "joined_on", "epoch")
 
-    def __init__(self, lane, stream):
+    def __init__(self, lane, stream, epoch):
         self.lane, self.stream, self.joined = lane, stream, False
         self.joined_on = set()          # raw stream handles that have been made to wait for this forward
-        self.done = False               # the device was synchronised after it: every stream is behind it
+        self.epoch = epoch              # the model's synchronisation epoch it was issued in (see STTran._epoch)
 
 
 class PackedClips(dict):

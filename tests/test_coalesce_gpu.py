@@ -206,7 +206,7 @@ def test_join_under_a_second_stream_after_the_lane_was_reused():
         g = first["_group"]
         later = [m.forward_async(_cuda_entry(e)) for _ in range(3)]      # reuses first's lane: first's group is `joined`
         main_h = torch.cuda.current_stream().cuda_stream
-        assert g.joined and g.joined_on == {main_h} and not g.done
+        assert g.joined and g.joined_on == {main_h} and g.epoch == m._epoch
         with torch.cuda.stream(side):
             m.join(first)
             assert side.cuda_stream in g.joined_on                           # the side stream was really made to wait
@@ -219,7 +219,11 @@ def test_join_under_a_second_stream_after_the_lane_was_reused():
         for p in later:
             m.join(p)
     m.sync_check()
-    assert first["_group"].done is True
+    assert first["_group"].epoch < m._epoch                                  # a device synchronisation: every earlier group is done
+    n = len(first["_group"].joined_on)
+    with torch.cuda.stream(side):
+        m.join(first)                                                        # ... so this is free under any stream
+    assert len(first["_group"].joined_on) == n
 
 
 def test_entries_queued_under_another_stream_precede_the_group_forward():

@@ -298,8 +298,15 @@ def test_gemm_stream_k_reuse_stress(lib, M, N, K, tile):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), it
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 2048), (2816, 1936, 1936), (1, 4, 32), (257, 130, 100), (5280, 2048, 1936)])
-def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
+X3_HOOKS = ["sttran_debug_gemm_emulated", "sttran_debug_gemm_emulated_t16"]     # round 2's kernel / the 16x16x32 tiles of round 6
+
+
+@pytest.mark.parametrize("hook,M,N,K", [(X3_HOOKS[0], 300, 512, 2048), (X3_HOOKS[0], 2816, 1936, 1936), (X3_HOOKS[0], 1, 4, 32),
+                                        (X3_HOOKS[0], 257, 130, 100), (X3_HOOKS[0], 5280, 2048, 1936),
+                                        (X3_HOOKS[1], 300, 512, 2048), (X3_HOOKS[1], 2816, 1936, 1936), (X3_HOOKS[1], 1, 176, 32),
+                                        (X3_HOOKS[1], 257, 352, 100), (X3_HOOKS[1], 5280, 2048, 1936), (X3_HOOKS[1], 40000, 176, 64),
+                                        (X3_HOOKS[1], 330, 5808, 1936), (X3_HOOKS[1], 1031, 128, 2376)])
+def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, hook, M, N, K):
     """the experimental bf16x3 engine (three bf16 planes per operand, six cross products, fp32 accumulate) must be as
     close to an fp64 reference as the exact-fp32 MFMA engine is -- it is an emulation of fp32, not a reduced precision"""
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -310,7 +317,7 @@ def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
     b = torch.randn(N, device="cuda", generator=g)
     res = torch.randn(M, N, device="cuda", generator=g)
     C3 = torch.full((M, N), float("nan"), device="cuda")
-    assert lib.sttran_debug_gemm_emulated(_p(A), Kp, None, _p(W), K, _p(b), _p(res), _p(C3), M, N, K, 1, None) == 0
+    assert getattr(lib, hook)(_p(A), Kp, None, _p(W), K, _p(b), _p(res), _p(C3), M, N, K, 1, None) == 0
     Wp = torch.zeros(N, Kp, device="cuda"); Wp[:, :K] = W
     C1 = torch.full((M, N), float("nan"), device="cuda")
     assert lib.sttran_debug_gemm_padded(_p(A), Kp, None, _p(Wp), Kp, _p(b), _p(res), _p(C1), M, N, K, 1, 0, None) == 0
@@ -322,8 +329,9 @@ def test_gemm_bf16x3_emulation_is_fp32_accurate(lib, M, N, K):
     assert e3 <= 2.0 * e1 + 1e-6, (e3, e1)
 
 
+@pytest.mark.parametrize("hook", X3_HOOKS)
 @pytest.mark.parametrize("a_scale,w_scale", [(1e-30, 1e20), (1e20, 1e-30), (1e-20, 1e-10), (1e18, 1e18), (1e-3, 1e3)])
-def test_gemm_bf16x3_operand_ranges(lib, a_scale, w_scale):
+def test_gemm_bf16x3_operand_ranges(lib, hook, a_scale, w_scale):
     """the emulation splits x = x1 + x2 + x3 into bf16 planes: x3 = bf16(x - x1 - x2) sits 16 binades below x, so it
     leaves the bf16 normal range 16 binades before fp32 does.  Operands far from 1 in both directions (products kept
     inside the fp32 range): the error against fp64, relative to sum |a||b|, stays at the exact engine's level."""
@@ -333,7 +341,7 @@ def test_gemm_bf16x3_operand_ranges(lib, a_scale, w_scale):
     W = (torch.randn(N, K, device="cuda", generator=g) * w_scale).contiguous()
     C3 = torch.full((M, N), float("nan"), device="cuda")
     C1 = torch.full((M, N), float("nan"), device="cuda")
-    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert getattr(lib, hook)(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
     assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
     torch.cuda.synchronize()
     ref = A[:M].double() @ W.double().T
@@ -345,7 +353,8 @@ def test_gemm_bf16x3_operand_ranges(lib, a_scale, w_scale):
     assert e3 <= 4.0 * e1 + 1e-8, (e3, e1)
 
 
-def test_gemm_bf16x3_cancellation(lib):
+@pytest.mark.parametrize("hook", X3_HOOKS)
+def test_gemm_bf16x3_cancellation(lib, hook):
     """mixed signs with heavy cancellation: every output is the difference of two nearly equal large sums, so an engine
     that lost low-order bits of the operands would show it.  a = [u | -u + d], w = [v | v]: a . w = d . v exactly in real
     arithmetic, |d| ~ 1e-4 |u|"""
@@ -357,7 +366,7 @@ def test_gemm_bf16x3_cancellation(lib):
     v = torch.randn(N, K // 2, device="cuda", generator=g)
     W = torch.cat([v, v], dim=1).contiguous()
     C3 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
-    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert getattr(lib, hook)(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
     assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
     torch.cuda.synchronize()
     ref = A[:M].double() @ W.double().T
@@ -367,7 +376,8 @@ def test_gemm_bf16x3_cancellation(lib):
     assert e1 < 0.05 and e3 <= 2.0 * e1 + 1e-3, (e3, e1)
 
 
-def test_gemm_bf16x3_subnormal_tail_is_documented(lib):
+@pytest.mark.parametrize("hook", X3_HOOKS)
+def test_gemm_bf16x3_subnormal_tail_is_documented(lib, hook):
     """where the emulation STOPS being fp32: operands below ~2^-110 have their third plane (and then the second) in the
     bf16 subnormal range, which the matrix pipe flushes -- the result degrades towards single-bf16 precision while the
     exact engine (whose products here are still normal fp32 numbers) keeps its accuracy.  Pinned so that a change of
@@ -378,7 +388,7 @@ def test_gemm_bf16x3_subnormal_tail_is_documented(lib):
     A = (torch.randn(M + 1, K, device="cuda", generator=g) * 1e-36).contiguous()
     W = (torch.randn(N, K, device="cuda", generator=g) * 1e30).contiguous()
     C3 = torch.empty(M, N, device="cuda"); C1 = torch.empty(M, N, device="cuda")
-    assert lib.sttran_debug_gemm_emulated(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+    assert getattr(lib, hook)(_p(A), K, None, _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
     assert lib.sttran_debug_gemm_padded(_p(A), K, None, _p(W), K, None, None, _p(C1), M, N, K, 0, 0, None) == 0
     torch.cuda.synchronize()
     ref = A[:M].double() @ W.double().T
@@ -388,6 +398,28 @@ def test_gemm_bf16x3_subnormal_tail_is_documented(lib):
     assert e1 < 2e-6                                           # the exact engine is unaffected
     assert e3 < 1e-2                                           # the emulation: still a bf16-grade answer, no NaN / Inf
     assert torch.isfinite(C3).all()
+
+
+def test_gemm_bf16x3_t16_gathered_rows_and_determinism(lib):
+    """the 16x16x32 kernel with a gathered A operand (the gather happens in the split pass), a row count that is no
+    multiple of the 128-row tile or the 16-row block, stream-K ranges (176 columns x many K-steps) -- bit-identical on repeat"""
+    M, N, K, R = 1000, 1936, 2048, 700
+    g = torch.Generator(device="cuda").manual_seed(17)
+    A = torch.randn(R, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    idx = torch.randint(0, R, (M,), device="cuda", generator=g, dtype=torch.int32)
+    outs = []
+    for _ in range(3):
+        C3 = torch.full((M, N), float("nan"), device="cuda")
+        assert lib.sttran_debug_gemm_emulated_t16(_p(A), K, _p(idx), _p(W), K, None, None, _p(C3), M, N, K, 0, None) == 0
+        outs.append(C3)
+    torch.cuda.synchronize()
+    ref = A.double()[idx.long()] @ W.double().T
+    assert (outs[0].double() - ref).abs().max().item() < 2e-3 and torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # a shape the tiles do not serve is refused, not mis-computed
+    C = torch.empty(8, 100, device="cuda")
+    assert lib.sttran_debug_gemm_emulated_t16(_p(A), K, None, _p(W), K, None, None, _p(C), 8, 100, K, 0, None) != 0
 
 
 # ---- DSG-DETR on the device: class sequences (lib/dsg_detr.py:545-555) and attention over lengths the host never sees ---
@@ -594,9 +626,11 @@ def test_mask_conv1_pool_propagates_nan_like_torch(lib):
     b0 = torch.rand(128, device="cuda", generator=g) - 0.5
     scale = torch.rand(128, device="cuda", generator=g) + 0.5
     shift = torch.rand(128, device="cuda", generator=g) - 0.5
-    ref = F.conv2d(masks, w0, b0, stride=2, padding=3)
+    # the reference's semantics are torch-CPU's (a GPU library's pooling need not propagate NaN): computed on the host
+    mc, wc, bc, sc, tc = (t.cpu() for t in (masks, w0, b0, scale, shift))
+    ref = F.conv2d(mc, wc, bc, stride=2, padding=3)
     ref = torch.where(torch.isnan(ref), ref, ref.clamp_min(0))
-    ref = F.max_pool2d(ref * scale[None, :, None, None] + shift[None, :, None, None], 3, 2, 1).permute(0, 2, 3, 1)
+    ref = F.max_pool2d(ref * sc[None, :, None, None] + tc[None, :, None, None], 3, 2, 1).permute(0, 2, 3, 1).cuda()
     out = torch.zeros(3, 7, 7, 128, device="cuda")
     assert lib.sttran_debug_mask_conv1_pool(_p(masks), None, _p(_pack_w0(w0, b0)), _p(scale), _p(shift), _p(out), 3, None) == 0
     torch.cuda.synchronize()
