@@ -110,7 +110,7 @@ int sttran_debug_gemm_emulated_t16(const float* A, int64_t lda, const int32_t* a
   EpiLinear e = epi_plain(C, N, bias, relu);
   e.res = residual; e.ldres = N;
   if (!x3t16_tile((int)N, e)) return STTRAN_ERR_INVALID;
-  if (split_fm(s, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb) != hipSuccess) return STTRAN_ERR_HIP;
+  if (split_fm(s, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb, 1) != hipSuccess) return STTRAN_ERR_HIP;
   if (split_fm(s, A, lda, a_rowidx, nullptr, (int)M, (int)K, pa) != hipSuccess) return STTRAN_ERR_HIP;
   hipError_t err = gemm_linear_x3t16(s, pa, pb, (int)((N + 15) / 16), (int)M, (int)N, (int)K, e, slab);
   return err == hipSuccess ? STTRAN_OK : STTRAN_ERR_HIP;
@@ -132,7 +132,7 @@ int sttran_debug_x3t16_bench(const float* A, int64_t lda, const float* Wt, int64
   if (hipMalloc(&pa, fm_planes_bytes(M, K) + 256) != hipSuccess || hipMalloc(&pb, fm_planes_bytes(N, K) + 256) != hipSuccess) goto out;
   hipEventCreate(&e0); hipEventCreate(&e1);
   if (!x3t16_tile((int)N, e)) { rc = STTRAN_ERR_INVALID; goto out2; }
-  if (split_fm(nullptr, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb) != hipSuccess) goto out2;
+  if (split_fm(nullptr, Wt, ldw, nullptr, nullptr, (int)N, (int)K, pb, 1) != hipSuccess) goto out2;
   if (split_fm(nullptr, A, lda, nullptr, nullptr, (int)M, (int)K, pa) != hipSuccess) goto out2;
   for (int i = 0; i < 3; ++i)
     if (gemm_linear_x3t16(nullptr, pa, pb, (int)((N + 15) / 16), (int)M, (int)N, (int)K, e, slab) != hipSuccess) goto out2;

@@ -20,6 +20,26 @@ const char* tile_name(int tile) {
   }
 }
 
+// bf16x3 engine: is this launch served by the emulation at all (sttran_set_gemm_engine; >= 512 rows unless BF16X3_ALL)
+static bool x3_on(const SttranHandle* h, int M) {
+  return h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && (M >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
+}
+// fragment-major planes of the weight rows [Wt, Wt + N) (a whole GEMM weight or a 16-row-aligned row range of one: the last
+// decoder layer projects k|v and q separately); row_blocks = 16-row blocks available from there.  nullptr: not served.
+static const void* fm_weight(SttranHandle* h, const float* Wt, int N, int K, int& row_blocks) {
+  for (auto& kv : h->w) {
+    const Tensor& t = kv.second;
+    if (!t.planes_fm || !t.ld || t.ld != pad32(K)) continue;
+    const int64_t rows = t.shape[0];
+    if (Wt < t.d || Wt >= t.d + rows * t.ld) continue;
+    const int64_t r0 = (Wt - t.d) / t.ld;
+    if ((Wt - t.d) % t.ld || r0 + N > rows || (r0 & 15)) return nullptr;
+    row_blocks = (int)((rows + 15) / 16 - r0 / 16);
+    return reinterpret_cast<const uint16_t*>(t.planes_fm) + (r0 / 16) * ((K + 31) / 32) * 1536;
+  }
+  return nullptr;
+}
+
 // C = act(A W^T + ...) through the planner; slab workspace grown on demand
 int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, int M, int N, int K, EpiLinear epi,
                int force_tile, int force_split) {
@@ -34,27 +54,23 @@ int run_linear(SttranHandle* h, hipStream_t s, GemmOperand A, const float* Wt, i
     // (1) the 16x16x32 tiles on pre-split fragment-major operands (gemm_bf16x3_t16.h): N a multiple of 176 or 128, K <= 4096
     //     (vr_fc's K = 12 544 operand would need 0.85 GB of planes: it stays on the in-loader split below), one gather table
     const int t16 = (K <= 4096 && !(A.aux > 0)) ? x3t16_tile(N, epi) : 0;
-    if (t16) {
-      for (auto& kv : h->w) {
-        const Tensor& t = kv.second;
-        if (!t.planes_fm || !t.ld || t.ld != pad32(K)) continue;
-        const int64_t rows = t.shape[0];
-        if (Wt < t.d || Wt >= t.d + rows * t.ld) continue;
-        const int64_t r0 = (Wt - t.d) / t.ld;
-        if ((Wt - t.d) % t.ld || r0 + N > rows || (r0 & 15)) break;
+    int wrb = 0;
+    const void* wfm = t16 ? fm_weight(h, Wt, N, K, wrb) : nullptr;
+    if (wfm) {
+      // the activation planes: a LayerNorm wrote them already (run_layernorm), else one split pass
+      const bool have = !A.rowidx && !A.rowoff && A.ptr == h->L->hplanes_of && M <= h->L->hplanes_rows && K == h->cfg.embed_dim;
+      if (!have) {
         const size_t need = fm_planes_bytes(M, K) + 256;
         if (need > h->L->aplanes.bytes) {
           HIPCK(hipStreamSynchronize(s));
           HIPCK(h->L->aplanes.ensure(need + need / 4));
         }
-        const int kb = (K + 31) / 32;
-        ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
-                     std::string("gemm16x3_kernel<Tile16<") + tile_name(t16) + ">,EpiLinear> + split_fm_kernel", M, N, K);
-        HIPCK(split_fm(s, A.ptr, A.ld, A.rowidx, A.rowoff, M, K, h->L->aplanes.p));
-        HIPCK(gemm_linear_x3t16(s, h->L->aplanes.p, reinterpret_cast<const uint16_t*>(t.planes_fm) + (r0 / 16) * kb * 1536,
-                                (int)((rows + 15) / 16 - r0 / 16), M, N, K, epi, h->L->slab.as<float>()));
-        return STTRAN_OK;
       }
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, N, K), gemm_bytes(M, N, K),
+                   std::string("gemm16x3_kernel<Tile16<") + tile_name(t16) + (have ? ">,EpiLinear>" : ">,EpiLinear> + split_fm_kernel"), M, N, K);
+      if (!have) HIPCK(split_fm(s, A.ptr, A.ld, A.rowidx, A.rowoff, M, K, h->L->aplanes.p));
+      HIPCK(gemm_linear_x3t16(s, have ? h->L->hplanes.p : h->L->aplanes.p, wfm, wrb, M, N, K, epi, h->L->slab.as<float>()));
+      return STTRAN_OK;
     }
     // (2) round 2's kernel (gemm_bf16x3.h): activations split by the A loader
     if (Wt == h->fc_w && h->fc_planes) {               // the grouped subj_fc | obj_fc launch (a derived tensor, not in h->w)
@@ -95,6 +111,57 @@ EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu) {
   return e;
 }
 
+int run_layernorm(SttranHandle* h, hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int M) {
+  const int D = h->cfg.embed_dim;
+  const int64_t LD = pad32(D);
+  void* planes = nullptr;
+  if (x3_on(h, M)) {
+    const size_t need = fm_planes_bytes(M, D) + 256;
+    if (need > h->L->hplanes.bytes) {
+      HIPCK(hipStreamSynchronize(s));
+      HIPCK(h->L->hplanes.ensure(need + need / 4));
+    }
+    planes = h->L->hplanes.p;
+  }
+  h->L->hplanes_of = planes ? y : nullptr;
+  h->L->hplanes_rows = planes ? M : 0;
+  ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D, planes ? "layernorm_kernel<planes>" : "layernorm_kernel", M, D, 0);
+  HIPCK(launch_layernorm(s, x, LD, gamma, beta, y, LD, M, D, planes));
+  return STTRAN_OK;
+}
+
+int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2) {
+  const int D = h->cfg.embed_dim, F = h->cfg.ffn_dim;
+  const int64_t LD = pad32(D), LF = pad32(F);
+  int rb1 = 0, rb2 = 0;
+  const void *w1 = nullptr, *w2 = nullptr;
+  if (x3_on(h, M) && F % 128 == 0 && F <= 4096 && x3t16_tile(D, e2) &&
+      (w1 = fm_weight(h, W(h, p + ".linear1.weight"), F, D, rb1)) && (w2 = fm_weight(h, W(h, p + ".linear2.weight"), D, F, rb2))) {
+    const bool have = x == h->L->hplanes_of && M <= h->L->hplanes_rows;
+    const size_t need_a = have ? 0 : fm_planes_bytes(M, D) + 256, need_f = fm_planes_bytes(M, F) + 256;
+    if (need_a > h->L->aplanes.bytes || need_f > h->L->f1planes.bytes || gemm_slab_bytes() > h->L->slab.bytes) {
+      HIPCK(hipStreamSynchronize(s));
+      if (need_a > h->L->aplanes.bytes) HIPCK(h->L->aplanes.ensure(need_a + need_a / 4));
+      if (need_f > h->L->f1planes.bytes) HIPCK(h->L->f1planes.ensure(need_f + need_f / 4));
+      HIPCK(h->L->slab.ensure(gemm_slab_bytes()));
+    }
+    {
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, F, D), gemm_bytes(M, F, D),
+                   std::string("gemm16x3_kernel<Tile16<128,128>,EpiActPlanes>") + (have ? "" : " + split_fm_kernel"), M, F, D);
+      if (!have) HIPCK(split_fm(s, x, LD, nullptr, nullptr, M, D, h->L->aplanes.p));
+      HIPCK(gemm_act_planes_x3t16(s, have ? h->L->hplanes.p : h->L->aplanes.p, w1, rb1, M, F, D, W(h, p + ".linear1.bias"), 1,
+                                  h->L->f1planes.p, h->L->slab.as<float>()));
+    }
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, D, F), gemm_bytes(M, D, F), "gemm16x3_kernel<Tile16<128,176>,EpiLinear>", M, D, F);
+    HIPCK(gemm_linear_x3t16(s, h->L->f1planes.p, w2, rb2, M, D, F, e2, h->L->slab.as<float>()));
+    return STTRAN_OK;
+  }
+  int rc;
+  if ((rc = run_linear(h, s, GemmOperand{x, LD, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
+                       epi_plain(f1, LF, W(h, p + ".linear1.bias"), 1)))) return rc;
+  return run_linear(h, s, GemmOperand{f1, LF, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2);
+}
+
 // One post-norm encoder layer over ragged sequences (lib/transformer.py:20-30; also the stock
 // nn.TransformerEncoderLayer of lib/dsg_detr.py:502-506 -- same sub-module names):
 //   h = LN1(x + MHA(x,x,x));  out = LN2(h + W2 relu(W1 h + b1) + b2)
@@ -102,8 +169,8 @@ EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu) {
 int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, const float* xin, float* xout, int M,
                       const int* seq_off, const int* seq_len, int nseq, int maxlen, bool len_on_device) {
   const SttranConfig& c = h->cfg;
-  const int D = c.embed_dim, F = c.ffn_dim;
-  const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (xin / xout included)
+  const int D = c.embed_dim;
+  const int64_t LD = pad32(D);                    // row stride of the [*, D] workspace buffers (xin / xout included)
   float* QKV = h->L->qkv.as<float>(); float* ATT = h->L->att.as<float>(); float* Y = h->L->ybuf.as<float>();
   float* H = h->L->hbuf.as<float>(); float* F1 = h->L->f1.as<float>();
   int rc;
@@ -117,20 +184,12 @@ int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, cons
   EpiLinear eo = epi_plain(Y, LD, W(h, p + ".self_attn.out_proj.bias"));
   eo.res = xin; eo.ldres = LD;
   if ((rc = run_linear(h, s, GemmOperand{ATT, LD, nullptr}, W(h, p + ".self_attn.out_proj.weight"), M, D, D, eo))) return rc;
-  {
-    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D, "layernorm_kernel", M, D, 0);
-    HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, LD, M, D));
-  }
-  if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), M, F, D,
-                       epi_plain(F1, LF, W(h, p + ".linear1.bias"), 1)))) return rc;
+  if ((rc = run_layernorm(h, s, Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), H, M))) return rc;
   EpiLinear e2 = epi_plain(Y, LD, W(h, p + ".linear2.bias"));
   e2.res = H; e2.ldres = LD;
-  if ((rc = run_linear(h, s, GemmOperand{F1, LF, nullptr}, W(h, p + ".linear2.weight"), M, D, F, e2))) return rc;
-  {
-    ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * M * D, "layernorm_kernel", M, D, 0);
-    HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, LD, M, D));
-  }
-  return STTRAN_OK;
+  if ((rc = run_ffn(h, s, p, H, F1, M, e2))) return rc;
+  // (its planes serve whoever projects `xout` next: the first decoder layer's q|k|v, a following encoder layer's in_proj)
+  return run_layernorm(h, s, Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), xout, M);
 }
 
 int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, hipStream_t s) {
@@ -191,7 +250,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       HIPCK(split_planes(s, t.d, t.ld, (int)t.shape[0], (int)t.shape[1], t.planes, t.ld));
       // ... and fragment-major (gemm_bf16x3_t16.h): [ceil(rows / 16)][ceil(cols / 32)][3][512], zero beyond rows / cols
       if (!t.planes_fm) HIPCK(hipMalloc(&t.planes_fm, fm_planes_bytes(t.shape[0], t.shape[1]) + 256));
-      HIPCK(split_fm(s, t.d, t.ld, nullptr, nullptr, (int)t.shape[0], (int)t.shape[1], t.planes_fm));
+      HIPCK(split_fm(s, t.d, t.ld, nullptr, nullptr, (int)t.shape[0], (int)t.shape[1], t.planes_fm, 1));
     }
     {   // the 1x1 union conv's weight [256, feat_dim, 1, 1] is a [256, feat_dim] GEMM operand too (feat_dim % 32 == 0)
       Tensor& t = h->w["union_func1.weight"];
@@ -214,6 +273,8 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
     if (h->lanes.size() > 1) HIPCK(hipStreamSynchronize(s));      // the other lanes' streams read the planes too
   }
   if ((rc = ensure_workspace(h, P, B))) return rc;
+  h->L->hplanes_of = nullptr;      // bf16x3 engine: LayerNorm planes of an earlier call mirror nothing of this one
+  h->L->hplanes_rows = 0;
 
   // ---- per-frame pair counts ---------------------------------------------------------------
   std::vector<int32_t> counts;
@@ -359,8 +420,8 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
   int64_t* union_off = feat_off + 2 * P;              // [P]
   int64_t* mask_off = feat_off + 3 * P;               // [P]
 
-  const int D = c.embed_dim, F = c.ffn_dim, FD = c.feat_dim, NC = c.num_obj_classes;
-  const int64_t LD = pad32(D), LF = pad32(F);     // row strides of the [*, D] / [*, F] workspace buffers (ensure_workspace)
+  const int D = c.embed_dim, FD = c.feat_dim, NC = c.num_obj_classes;
+  const int64_t LD = pad32(D);                    // row stride of the [*, D] workspace buffers (ensure_workspace)
   float* X0 = h->L->x0.as<float>();
   float* QKV = h->L->qkv.as<float>(); float* ATT = h->L->att.as<float>(); float* Y = h->L->ybuf.as<float>();
   float* H = h->L->hbuf.as<float>(); float* F1 = h->L->f1.as<float>(); float* G = h->L->gbuf.as<float>();
@@ -546,15 +607,10 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       eo.res = G; eo.ldres = LD; eo.res_rowidx = rows;
       if (i == 0 && !need_g0) { eo.res = UNI; eo.res_rowidx = dec_src; }      // residual = the window token's encoder row
       if ((rc = run_linear(h, s, GemmOperand{ATT, LD, rows, 0, nullptr, NT}, W(h, p + ".multihead2.out_proj.weight"), MQ, D, D, eo))) return rc;
-      {
-        ProfScope ps(h, s, STTRAN_PROF_LAYERNORM, 0, 8.0 * MQ * D, "layernorm_kernel", MQ, D, 0);
-        HIPCK(launch_layernorm(s, Y, LD, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, LD, MQ, D));
-      }
-      if ((rc = run_linear(h, s, GemmOperand{H, LD, nullptr}, W(h, p + ".linear1.weight"), MQ, F, D,
-                           epi_plain(F1, LF, W(h, p + ".linear1.bias"), 1)))) return rc;
+      if ((rc = run_layernorm(h, s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, MQ))) return rc;
       EpiLinear e2 = epi_plain(last ? UDEC : G, LD, W(h, p + ".linear2.bias"));
       e2.res = H; e2.ldres = LD;
-      if ((rc = run_linear(h, s, GemmOperand{F1, LF, nullptr}, W(h, p + ".linear2.weight"), MQ, D, F, e2))) return rc;
+      if ((rc = run_ffn(h, s, p, H, F1, MQ, e2))) return rc;
     }
   } else if (NT > 0) {
     // dec_layers == 0: windows pass through -- the needed rows are encoder rows

@@ -109,7 +109,12 @@ struct DecLayer { float* posbias = nullptr; };   // [2][2*D]
 struct Lane {
   int64_t capP = 0, capB = 0;
   sttran_host::DevBuf x0, qkv, att, ybuf, hbuf, f1, gbuf, uni, vbuf, c2, slab, idx, zbuf, hobj, ebuf;
-  sttran_host::DevBuf aplanes;  // bf16x3 engine: fragment-major planes of the activation operand of the GEMM in flight
+  // bf16x3 engine, fragment-major planes (gemm_bf16x3_t16.h): aplanes = the activation operand of the GEMM in flight (made by
+  // split_fm in front of it); hplanes = a LayerNorm's output, written by the LayerNorm itself (`hplanes_of` = the fp32 row
+  // buffer it mirrors, `hplanes_rows` rows of it; 0 = stale); f1planes = linear1 -> ReLU, written by that GEMM's epilogue
+  sttran_host::DevBuf aplanes, hplanes, f1planes;
+  const float* hplanes_of = nullptr;
+  int64_t hplanes_rows = 0;
   sttran_host::DevBuf dsg;                   // DSG-DETR: class-sequence tables built on the device (launch_dsg_layout)
   sttran_host::DevBuf ctab, poff;            // chunk table of the call's inputs (kernels.h ChunkTable); per-pair element offsets [4 P] int64
   std::vector<int64_t> ctab_host;   // what ctab holds (re-uploaded only when a call's pointers / sizes differ)
@@ -227,6 +232,10 @@ EpiLinear epi_plain(float* C, int64_t ldc, const float* bias, int relu = 0);
 int run_encoder_layer(SttranHandle* h, hipStream_t s, const std::string& p, const float* xin, float* xout, int M,
                       const int* seq_off, const int* seq_len, int nseq, int maxlen, bool len_on_device = false);
 int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* out, hipStream_t s);
+// LayerNorm whose output the next GEMM reads: under the bf16x3 engine it also writes that GEMM's activation planes
+int run_layernorm(SttranHandle* h, hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int M);
+// y = res + linear2(relu(linear1(x))): two run_linear calls, or (bf16x3 engine) planes in, planes between, no split pass
+int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2);
 // ---- api_layout.hip
 int ensure_workspace(SttranHandle* h, int64_t P, int64_t B);
 int upload_staged(SttranHandle* h, hipStream_t s, const void* src, size_t bytes, void* dst);

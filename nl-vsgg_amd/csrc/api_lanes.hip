@@ -26,7 +26,7 @@ int lane_create(SttranHandle* h, Lane** out) {
 void lane_destroy(Lane* L) {
   if (!L) return;
   for (DevBuf* b : {&L->x0, &L->qkv, &L->att, &L->ybuf, &L->hbuf, &L->f1, &L->gbuf, &L->uni, &L->vbuf, &L->c2, &L->slab, &L->idx,
-                    &L->zbuf, &L->hobj, &L->ebuf, &L->dsg, &L->ctab, &L->poff, &L->aplanes})
+                    &L->zbuf, &L->hobj, &L->ebuf, &L->dsg, &L->ctab, &L->poff, &L->aplanes, &L->hplanes, &L->f1planes})
     b->release();
   for (int i = 0; i < Lane::kStages; ++i) {
     if (L->stage[i]) hipHostFree(L->stage[i]);

@@ -14,7 +14,12 @@
 //     back (3 KB).  Element (r, k) of plane p:  ((r / 16 * KB + k / 32) * 3 + p) * 512 + ((r % 16) + 16 * (k % 32 / 8)) * 8 + k % 8.
 //     So a fragment is ONE coalesced 1 KB load, an LDS image is a straight copy (no swizzle arithmetic: `ds_read_b128` of a
 //     lane-linear 1 KB block is conflict-free by construction of the instruction's lane groups), and a weight tile's K-step
-//     goes global -> LDS without passing registers (`global_load_lds_dwordx4`, one instruction per 1 KB block);
+//     goes global -> LDS without passing registers (`global_load_lds_dwordx4`, one instruction per 1 KB block).
+//     That lane-major order is the WEIGHTS' (they pass through LDS).  The ACTIVATION planes use the same blocks with the 1 KB
+//     of a plane ROW-major ([16 rows][32 k], 64 bytes per row: element (r, k) at (r % 16) * 32 + k % 32): their fragments go
+//     straight to registers, where any order inside the 1 KB is the same coalesced load, and a producer that holds a ROW
+//     (LayerNorm, a GEMM epilogue) writes 32-64 contiguous bytes per plane instead of 8 (measured: the lane-major
+//     LayerNorm variant took 130 us against 47 us without planes -- every 8-byte store its own 32-byte sector);
 //   * the A fragments never touch LDS: wave w owns rows 32 w .. 32 w + 31 of the tile and ALL its columns, so no other wave
 //     needs them -- six 1 KB loads per wave and K-step, straight into the registers the MFMAs read, one K-step ahead.
 //     LDS holds the weight tile only: 2 stages x (BN / 16) x 3 KB = 66 KB (176 columns), two workgroups per CU;
@@ -47,7 +52,7 @@ struct FmPlanes {
 // Row r of the operand: src + rowoff[r] (64-bit element offsets), else src + rowidx[r] * ld, else src + r * ld.
 static __global__ void __launch_bounds__(256)
 split_fm_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __restrict__ rowidx, const int64_t* __restrict__ rowoff,
-                int M, int K, int kb_total, int64_t blocks, __bf16* __restrict__ planes) {
+                int M, int K, int kb_total, int64_t blocks, __bf16* __restrict__ planes, int row_major) {
   const int lane = threadIdx.x & 63;
   const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= blocks) return;
@@ -65,11 +70,42 @@ split_fm_kernel(const float* __restrict__ src, int64_t ld, const int32_t* __rest
   bf16x4 h0, m0, l0, h1, m1, l1;
   split3(v0, h0, m0, l0);
   split3(v1, h1, m1, l1);
-  __bf16* out = planes + blk * kFmBlock3 + lane * 8;
+  // weights: lane-major (lane * 16 bytes); activations: row-major inside the block (row * 64 + chunk * 16 bytes)
+  __bf16* out = planes + blk * kFmBlock3 + (row_major ? (lane & 15) * 32 + (lane >> 4) * 8 : lane * 8);
   *reinterpret_cast<bf16x8*>(out) = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
   *reinterpret_cast<bf16x8*>(out + kFmBlock) = bf16x8{m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
   *reinterpret_cast<bf16x8*>(out + 2 * kFmBlock) = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 }
+
+// bf16 element offset of (row, col) in plane 0 of ACTIVATION planes (row-major blocks) with kb_total K blocks per row block
+__device__ __forceinline__ int64_t fm_offset(int row, int col, int kb_total) {
+  return ((int64_t)(row >> 4) * kb_total + (col >> 5)) * kFmBlock3 + ((row & 15) << 5) + (col & 31);
+}
+// four consecutive columns (col % 4 == 0) of one row -> the three planes, 8 bytes each
+__device__ __forceinline__ void fm_store4(__bf16* planes, int kb_total, int row, int col, const f32x4& v) {
+  bf16x4 h, m, l;
+  split3(v, h, m, l);
+  __bf16* o = planes + fm_offset(row, col, kb_total);
+  *reinterpret_cast<bf16x4*>(o) = h;
+  *reinterpret_cast<bf16x4*>(o + kFmBlock) = m;
+  *reinterpret_cast<bf16x4*>(o + 2 * kFmBlock) = l;
+}
+
+// Epilogue of a GEMM whose output is ONLY the next GEMM's activation operand (linear1 -> ReLU -> linear2,
+// lib/transformer.py:24,27,53,56): out = act(acc + bias) leaves as fragment-major planes -- 6 bytes per element instead of
+// 4 for an fp32 row nobody else reads, and no split pass in front of the next launch.
+struct EpiActPlanes {
+  static constexpr bool kVector = true;
+  const float* bias; __bf16* planes; int kb_total; int relu;
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+    v += *reinterpret_cast<const f32x4*>(bias + col);
+    if (relu) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = relu_nan(v[c]);
+    }
+    fm_store4(planes, kb_total, row, col, v);
+  }
+};
 
 // T = Tile16<128, 176> or Tile16<128, 128> (gemm_f32_t16.h: only BM, BN, NB, NT are used)
 template <class T>
@@ -124,7 +160,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rb = min(m0 / 16 + 2 * wave + i, A.rb_total - 1);
-      pa[i] = A.ptr + ((int64_t)rb * A.kb_total + ks0) * kFmBlock3 + lane * 8;
+      pa[i] = A.ptr + ((int64_t)rb * A.kb_total + ks0) * kFmBlock3 + (lane & 15) * 32 + (lane >> 4) * 8;   // row-major block
     }
     // LDS-DMA pieces of this wave: chunk c = wave + 4 q of the stage image [NB][3][1 KB] = (column block c / 3, plane c % 3)
     const __bf16* pb[X::CPW];
@@ -213,6 +249,18 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     // ---- epilogue: gemm16_kernel's (same accumulator layout: row = lane % 16 of block i, columns 4 (lane / 16) + {0..3} of block j)
     const int row0 = m0 + wave * 32 + fr;
     const int col0 = n0 + 4 * fg;
+    if constexpr (std::is_same<Epi, EpiActPlanes>::value) {
+      if (nsteps == ksteps) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = row0 + 16 * i;
+          if (r < M) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) epi.vec(r, col0 + 16 * j, acc[i][j]);
+          }
+        }
+      }
+    } else
     if (nsteps == ksteps) {
       const int rows2[2] = {row0, row0 + 16};
       const bool valid2[2] = {row0 < M, row0 + 16 < M};
@@ -252,7 +300,8 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
           }
         }
       }
-    } else {
+    }
+    if (nsteps != ksteps) {
       // partial K range: park the raw accumulators in gemm16_kernel's format (gemm16_fixup_kernel sums them)
       f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
 #pragma unroll

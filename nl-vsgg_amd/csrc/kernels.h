@@ -88,12 +88,17 @@ hipError_t launch_union_conv_x3(hipStream_t s, const float* U, const int64_t* u_
 // [row block 16][K block 32][plane 3][512] -- fm_planes_bytes(rows, K) bytes; split_fm makes them from fp32 rows (optionally
 // gathered: rowoff = 64-bit element offsets, else rowidx), zero beyond M rows / K columns
 size_t fm_planes_bytes(int64_t rows, int64_t K);
+// weight = 1: the lane-major order of a weight (it passes through LDS); 0: an activation operand (row-major blocks)
 hipError_t split_fm(hipStream_t s, const float* src, int64_t ld, const int32_t* rowidx, const int64_t* rowoff, int M, int K,
-                    void* planes);
+                    void* planes, int weight = 0);
 int x3t16_tile(int N, const EpiLinear& epi);          // TILE_128x176 / TILE_T128x128, or 0 = shape / epilogue not served
 // b_planes = the weight's planes at its first needed row block; b_row_blocks = row blocks available from there
 hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
                              const EpiLinear& epi, float* slab);
+
+// the same GEMM with out = act(A W^T + bias) written as the NEXT launch's fragment-major activation planes [M, N] (N % 32 == 0)
+hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                                 const float* bias, int relu, void* out_planes, float* slab);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // Where the inputs of one call live: n chunks, chunk c = the tensors of one clip as the caller passed them (SttranInputs'
@@ -154,8 +159,10 @@ hipError_t launch_union_boxes_masks(hipStream_t s, const float* boxes, const int
 
 // ---- transformer pieces ----------------------------------------------------------------------
 // x rows ldx floats apart, y rows ldy floats apart (the workspace keeps [*, 1936] activations at a row stride of 1952)
+// planes (optional, bf16x3 engine): y additionally leaves as fragment-major bf16 planes [rows, dim] (gemm_bf16x3_t16.h),
+// columns dim .. ceil32(dim) zero
 hipError_t launch_layernorm(hipStream_t s, const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                            int64_t ldy, int64_t rows, int dim);
+                            int64_t ldy, int64_t rows, int dim, void* planes = nullptr);
 // q_begin (optional, per sequence): compute only query rows [q_begin, len)
 // qkv rows are 3*dim floats apart, out rows ldo floats apart
 hipError_t launch_attention(hipStream_t s, const float* qkv, const int* seq_off, const int* seq_len,

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "gemm_bf16x3_t16.h"
 
 namespace sttran {
 
@@ -548,9 +549,13 @@ hipError_t launch_attention_classes(hipStream_t s, const float* qkv, const int* 
 // ------------------------------------------------------------------------------------------
 constexpr int kLnMaxV = 16;   // float4 per lane -> dim <= 4096
 
+// PLANES (bf16x3 engine): the normalised row additionally leaves as fragment-major bf16 planes (gemm_bf16x3_t16.h) -- the
+// activation operand of the GEMM behind the LayerNorm (linear1, the next layer's in_proj) without a split pass of its own
+template <bool PLANES>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
-                 const float* __restrict__ beta, float* __restrict__ y, int64_t ldy, int64_t rows, int dim) {
+                 const float* __restrict__ beta, float* __restrict__ y, int64_t ldy, int64_t rows, int dim,
+                 __bf16* __restrict__ planes, int kb_total) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -591,16 +596,26 @@ layernorm_kernel(const float* __restrict__ x, int64_t ldx, const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       yr[j] = o;
+      if constexpr (PLANES) fm_store4(planes, kb_total, (int)row, 4 * j, o);
+    } else if constexpr (PLANES) {
+      if (4 * j < kb_total * 32) fm_store4(planes, kb_total, (int)row, 4 * j, f32x4{0.f, 0.f, 0.f, 0.f});   // the K tail stays zero
     }
   }
 }
 
 hipError_t launch_layernorm(hipStream_t s, const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
-                            int64_t ldy, int64_t rows, int dim) {
+                            int64_t ldy, int64_t rows, int dim, void* planes) {
   if (rows <= 0) return hipSuccess;
   if ((dim & 3) || dim > kLnMaxV * 256 || (ldx & 3) || (ldy & 3) || ldx < dim || ldy < dim) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy,
-                     rows, dim);
+  const int kb = (dim + 31) / 32;
+  if (planes) {
+    if (kb * 32 > kLnMaxV * 256 || rows >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy,
+                       rows, dim, reinterpret_cast<__bf16*>(planes), kb);
+  } else {
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy,
+                       rows, dim, (__bf16*)nullptr, kb);
+  }
   return hipGetLastError();
 }
 

@@ -9,20 +9,19 @@ size_t fm_planes_bytes(int64_t rows, int64_t K) {
 }
 
 hipError_t split_fm(hipStream_t s, const float* src, int64_t ld, const int32_t* rowidx, const int64_t* rowoff, int M, int K,
-                    void* planes) {
+                    void* planes, int weight) {
   if (M <= 0 || K <= 0) return hipSuccess;
   if ((reinterpret_cast<uintptr_t>(src) & 15) || (ld & 3) || (reinterpret_cast<uintptr_t>(planes) & 15)) return hipErrorInvalidValue;
   const int kb = (K + 31) / 32;
   const int64_t blocks = (int64_t)((M + 15) / 16) * kb;
   hipLaunchKernelGGL(split_fm_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, src, ld, rowidx, rowoff, M, K, kb, blocks,
-                     reinterpret_cast<__bf16*>(planes));
+                     reinterpret_cast<__bf16*>(planes), weight ? 0 : 1);
   return hipGetLastError();
 }
 
-template <class T, int TILE_ID>
-static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes& B, int M, int N, int K, const EpiLinear& epi,
+template <class T, int TILE_ID, class Epi>
+static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes& B, int M, int N, int K, const Epi& e,
                                float* slab) {
-  using Epi = EpiLinearV;
   static DeviceMarks marks;
   auto kern = gemm16x3_kernel<T, Epi>;
   {
@@ -39,7 +38,6 @@ static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes&
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
   const int half = T::GROUP_N;
-  const Epi e{epi};
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
                      base, rem, half, slab, e);
   hipError_t err = hipGetLastError();
@@ -71,8 +69,23 @@ hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_
   const int kb = (K + 31) / 32;
   const FmPlanes A{reinterpret_cast<const __bf16*>(a_planes), kb, (M + 15) / 16};
   const FmPlanes B{reinterpret_cast<const __bf16*>(b_planes), kb, b_row_blocks};
-  if (tile == TILE_128x176) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, epi, slab);
-  return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, epi, slab);
+  if (tile == TILE_128x176) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, EpiLinearV{epi}, slab);
+  return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, EpiLinearV{epi}, slab);
+}
+
+// out_planes[M, N] (fragment-major, as the NEXT launch's activation operand) = act(A W^T + bias): linear1 -> ReLU of the FFN
+hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                                 const float* bias, int relu, void* out_planes, float* slab) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (!bias || !al16p(bias) || !al16p(a_planes) || !al16p(b_planes) || !al16p(out_planes) || b_row_blocks * 16 < N || (N & 31))
+    return hipErrorInvalidValue;
+  const int kb = (K + 31) / 32;
+  const FmPlanes A{reinterpret_cast<const __bf16*>(a_planes), kb, (M + 15) / 16};
+  const FmPlanes B{reinterpret_cast<const __bf16*>(b_planes), kb, b_row_blocks};
+  const EpiActPlanes e{bias, reinterpret_cast<__bf16*>(out_planes), N / 32, relu};
+  if (N % 176 == 0) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, e, slab);
+  if (N % 128 == 0) return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, e, slab);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace sttran
