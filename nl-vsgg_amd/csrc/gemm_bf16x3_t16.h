@@ -154,38 +154,43 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     tile_origin_rt(tile, tiles_m, tiles / tiles_m, half, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // this wave's two A row blocks (clamped: a tail block re-reads the last one, its rows are never stored) and the
-    // weight tile's first column block; per K-step both advance by one [16][32] block = 3 KB
-    const __bf16* pa[2];
+    // Operand addresses = a wave-UNIFORM 64-bit base (scalar registers: `wave` is a readfirstlane value) + a 32-bit per-lane
+    // byte offset: one VGPR for all of A's fragments and one for all LDS-DMA pieces, instead of a 64-bit pointer per piece
+    // (9 + 2 pointers = 22 VGPRs: with them the 176-column tile spilled).
+    // A: this wave's two row blocks (clamped: a tail block re-reads the last one, its rows are never stored), row-major
+    // blocks; B: the weight tile's column blocks; per K-step both advance by one [16][32] block = 3 KB.
+    const uint32_t lane_a = (uint32_t)(((lane & 15) * 32 + (lane >> 4) * 8) * 2), lane_b = (uint32_t)lane * 16u;
+    const char* a_base[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int rb = min(m0 / 16 + 2 * wave + i, A.rb_total - 1);
-      pa[i] = A.ptr + ((int64_t)rb * A.kb_total + ks0) * kFmBlock3 + (lane & 15) * 32 + (lane >> 4) * 8;   // row-major block
+      a_base[i] = reinterpret_cast<const char*>(A.ptr) + ((int64_t)rb * A.kb_total + ks0) * (kFmBlock3 * 2);
     }
-    // LDS-DMA pieces of this wave: chunk c = wave + 4 q of the stage image [NB][3][1 KB] = (column block c / 3, plane c % 3)
-    const __bf16* pb[X::CPW];
-#pragma unroll
-    for (int q = 0; q < X::CPW; ++q) {
+    const char* const b_base = reinterpret_cast<const char*>(B.ptr) + ((int64_t)(n0 / 16) * B.kb_total + ks0) * (kFmBlock3 * 2);
+    const int64_t b_cb = (int64_t)B.kb_total * (kFmBlock3 * 2);        // bytes between column blocks
+    // LDS-DMA piece q of this wave: chunk c = wave + 4 q of the stage image [NB][3][1 KB] = (column block c / 3, plane c % 3)
+    // (33 chunks over 4 waves x 9 pieces: the three pieces past the end re-stage the last chunk -- same bytes to the same
+    //  address -- instead of sitting under a wave-uniform branch: a branch ends the scheduling region, and with one around
+    //  every piece the fragment reads of block j + 1 were issued, and waited for, in FRONT of block j's MFMAs)
+    auto glds_piece = [&](int q, int step, unsigned char* stage) {
       const int c = min(wave + 4 * q, X::CHUNKS - 1);
-      const int cb = min(n0 / 16 + c / 3, B.rb_total - 1);
-      pb[q] = B.ptr + ((int64_t)cb * B.kb_total + ks0) * kFmBlock3 + (c % 3) * kFmBlock + lane * 8;
-    }
+      const char* src = b_base + (c / 3) * b_cb + (int64_t)step * (kFmBlock3 * 2) + (c % 3) * 1024;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lane_b),
+                                       (void __attribute__((address_space(3)))*)(stage + c * 1024), 16, 0, 0);
+    };
     auto stage_b = [&](int step, unsigned char* stage) {          // K-step `step` of the weight tile -> `stage`
 #pragma unroll
-      for (int q = 0; q < X::CPW; ++q) {
-        const int c = wave + 4 * q;
-        if (c < X::CHUNKS)                                          // (wave-uniform)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(pb[q] + (int64_t)step * kFmBlock3),
-                                           (void __attribute__((address_space(3)))*)(stage + c * 1024), 16, 0, 0);
-      }
+      for (int q = 0; q < X::CPW; ++q) glds_piece(q, step, stage);
     };
     bf16x8 fa[2][3][2];                                             // [set][plane][row block]
+    auto load_a1 = [&](int set, int step, int i, int pl) {
+      fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(a_base[i] + (int64_t)step * (kFmBlock3 * 2) + pl * 1024 + lane_a);
+    };
     auto load_a = [&](int set, int step) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          fa[set][p][i] = *reinterpret_cast<const bf16x8*>(pa[i] + (int64_t)step * kFmBlock3 + p * kFmBlock);
+        for (int pl = 0; pl < 3; ++pl) load_a1(set, step, i, pl);
     };
 
     f32x4 acc[2][NB];
@@ -193,10 +198,6 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    stage_b(0, smem_x3);
-    load_a(0, 0);
-    __syncthreads();                              // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
 
     bf16x8 fb[2][3];
     auto read_b = [&](const unsigned char* stage, int j, int buf) {
@@ -212,30 +213,52 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
         for (int i = 0; i < 2; ++i)      // weights on the "A" port: a lane holds 4 consecutive columns of one output row
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][PB[t]], fa[set][PA[t]][i], acc[i][j], 0, 0, 0);
     };
+    // one memory piece of the NEXT K-step: pieces 0 .. CPW-1 = this wave's LDS-DMA chunks, CPW .. CPW+5 = its A fragments
+    constexpr int NVM = X::CPW + 6;
+    auto vmem_piece = [&](int n, int set_next, int step, unsigned char* stage) {
+      if (n < X::CPW) glds_piece(n, step, stage);
+      else if (n < NVM) load_a1(set_next, step, (n - X::CPW) / 3, (n - X::CPW) % 3);
+    };
+
+    stage_b(0, smem_x3);
+    load_a(0, 0);
+    __syncthreads();                              // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+    read_b(smem_x3, 0, 0);
+
+    // One K-step.  On entry fb[par] holds column block 0's fragments (read behind the previous barrier).  Block j runs its 12
+    // MFMAs with the 3 fragment reads of block j + 1 and two memory pieces of the NEXT K-step between them (a piece = one 1 KB
+    // LDS-DMA chunk of the weight tile or one A fragment: 14-15 per wave, spread over the first blocks -- issued in one burst
+    // at the top of the step they held the wave for ~300 cycles before its first MFMA).  The LAST block is held over the
+    // barrier: its MFMAs run after the next step's first fragment reads have been issued and cover the barrier wait and
+    // their latency (gemm16_kernel does the same).  PAR = the fragment buffer of block 0: with an odd number of column
+    // blocks (11) consecutive steps start on alternating buffers.
     auto k_step = [&](int t, auto set_c) {
       constexpr int set = decltype(set_c)::value;
+      constexpr int par = (NB & 1) ? set : 0;
       const unsigned char* cur = smem_x3 + set * X::STAGE_BYTES;
       unsigned char* nxt = smem_x3 + (set ^ 1) * X::STAGE_BYTES;
       const int tn = t + 1 < nsteps ? t + 1 : t;                   // the last step re-loads itself (never consumed)
-      read_b(cur, 0, 0);
-      stage_b(tn, nxt);
-      load_a(set ^ 1, tn);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if (j + 1 < NB) read_b(cur, j + 1, (j + 1) & 1);
-        mma_block(set, j, j & 1);
-        if (j + 1 < NB) {
-          // 12 MFMAs of block j with the 3 fragment reads of block j + 1 spread between them
+      for (int j = 0; j + 1 < NB; ++j) {
+        read_b(cur, j + 1, (par + j + 1) & 1);
+        vmem_piece(2 * j, set ^ 1, tn, nxt);
+        vmem_piece(2 * j + 1, set ^ 1, tn, nxt);
+        mma_block(set, j, (par + j) & 1);
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        for (int r = 0; r < 3; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (r < 2 && 2 * j + r < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      static_assert(2 * (NB - 1) >= NVM, "the next K-step's memory pieces must fit the blocks in front of the held-over one");
       __syncthreads();                            // every wave has read `cur`; `nxt` and the next A fragments have landed
+      read_b(nxt, 0, (par + NB) & 1);
+      __builtin_amdgcn_sched_barrier(0);          // issue these reads BEFORE the held-over block, which then hides them
+      mma_block(set, NB - 1, (par + NB - 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
     };
     {
       int t = 0;
@@ -245,6 +268,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
       }
       if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
     }
+    __syncthreads();                              // the next item's prologue overwrites stage 0: every wave is out of the loop
 
     // ---- epilogue: gemm16_kernel's (same accumulator layout: row = lane % 16 of block i, columns 4 (lane / 16) + {0..3} of block j)
     const int row0 = m0 + wave * 32 + fr;
