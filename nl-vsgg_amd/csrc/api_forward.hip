@@ -258,6 +258,8 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       if (t.d) {
         if (!t.planes) HIPCK(hipMalloc(&t.planes, (size_t)3 * 256 * FDp * 2 + 256));
         HIPCK(split_planes(s, t.d, FDp, 256, (int)FDp, t.planes, FDp));
+        if (!t.planes_fm) HIPCK(hipMalloc(&t.planes_fm, fm_planes_bytes(256, FDp) + 256));
+        HIPCK(split_fm(s, t.d, FDp, nullptr, nullptr, 256, (int)FDp, t.planes_fm, 1));
       }
     }
     if (h->fc_w) {      // stacked subj_fc | obj_fc weight of the grouped launch
@@ -268,6 +270,8 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
     if (h->w4_perm) {   // conv3x3 weight in its (ky, kx, ci) K order
       if (!h->w4_planes) HIPCK(hipMalloc(&h->w4_planes, (size_t)3 * 256 * 1152 * 2 + 256));
       HIPCK(split_planes(s, h->w4_perm, 1152, 256, 1152, h->w4_planes, 1152));
+      if (!h->w4_planes_fm) HIPCK(hipMalloc(&h->w4_planes_fm, fm_planes_bytes(256, 1152) + 256));
+      HIPCK(split_fm(s, h->w4_perm, 1152, nullptr, nullptr, 256, 1152, h->w4_planes_fm, 1));
     }
     h->planes_ready = true;
     if (h->lanes.size() > 1) HIPCK(hipStreamSynchronize(s));      // the other lanes' streams read the planes too
@@ -478,15 +482,15 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                                    h->bn1_shift, C2, (int)P));
     }
     EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
-    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && h->w4_planes &&
+    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && h->w4_planes_fm &&
                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
-                 x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_CONV2>,EpiConvRows>"
+                 x3 ? "gemm16x3c_kernel<Tile16<128,128>,AC_CONV2,EpiConvRows>"
                     : conv_t16 ? "gemm16c_kernel<Tile16C<B_CONV2>,EpiConvT16>"
                                : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
     if (x3)
-      HIPCK(launch_mask_conv2_x3(s, h->w4_planes, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
-                                 h->L->slab.as<float>()));
+      HIPCK(launch_mask_conv2_x3t16(s, h->w4_planes_fm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
+                                    h->L->slab.as<float>()));
     else if (conv_t16)
       HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->L->slab.as<float>()));
 #ifdef STTRAN_GEMM_EXPERIMENT
@@ -498,15 +502,15 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
   }
   {
     const Tensor& wu = h->w["union_func1.weight"];
-    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes &&
+    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes_fm && FD % 32 == 0 &&
                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
     ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
-                 x3 ? "gemm_x3_kernel<X3Tile<128,256,2,4,A_UNION_FLAT>,EpiUnionRows>"
+                 x3 ? "gemm16x3c_kernel<Tile16<128,128>,AC_UNION,EpiUnionRows>"
                     : conv_t16 ? "gemm16c_kernel<Tile16C<B_UNION_FLAT>,EpiUnionT16>"
                                : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
     if (x3)
-      HIPCK(launch_union_conv_x3(s, union_base, union_off, wu.planes, W(h, "union_func1.bias"), V, (int)P, FD,
-                                 h->L->slab.as<float>()));
+      HIPCK(launch_union_conv_x3t16(s, union_base, union_off, wu.planes_fm, W(h, "union_func1.bias"), V, (int)P, FD,
+                                    h->L->slab.as<float>()));
     else if (conv_t16)
       HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                                   h->L->slab.as<float>()));

@@ -161,6 +161,7 @@ struct SttranHandle {
   float *heads_w = nullptr, *heads_b = nullptr, *w0_perm = nullptr, *w4_perm = nullptr;
   float *fc_w = nullptr, *fc_b = nullptr;   // [subj_fc ; obj_fc] stacked: weights [1024, feat_dim], bias [1024] (one grouped launch)
   void* w4_planes = nullptr;    // bf16x3 engine: [3][256][1152] bf16 planes of w4_perm (made on demand)
+  void* w4_planes_fm = nullptr; // ... and its fragment-major planes (gemm_bf16x3_t16c.h)
   void* fc_planes = nullptr;    // ... [3][1024][feat_dim] planes of the stacked subj_fc | obj_fc weight
   float *oc_pos_scale = nullptr, *oc_pos_shift = nullptr, *oc_bn_scale = nullptr, *oc_bn_shift = nullptr;
   std::vector<sttran_host::DecLayer> dec;

@@ -159,6 +159,7 @@ void sttran_destroy(SttranHandle* h) {
     if (kv.second.planes_fm) hipFree(kv.second.planes_fm);
   }
   if (h->w4_planes) hipFree(h->w4_planes);
+  if (h->w4_planes_fm) hipFree(h->w4_planes_fm);
   if (h->fc_planes) hipFree(h->fc_planes);
   h->derived.release();
   for (Lane* L : h->lanes) lane_destroy(L);

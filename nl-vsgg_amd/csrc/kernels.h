@@ -100,6 +100,13 @@ hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_
 hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
                                  const float* bias, int relu, void* out_planes, float* slab);
 
+// the two convolutions on the same engine (gemm_bf16x3_t16c.h): planes_fm = fragment-major planes (split_fm, weight = 1) of the
+// [256, K] / [256, 1152] weight
+hipError_t launch_union_conv_x3t16(hipStream_t s, const float* U, const int64_t* u_off, const void* planes_fm, const float* bias,
+                                   float* V, int P, int K, float* slab);
+hipError_t launch_mask_conv2_x3t16(hipStream_t s, const void* planes_fm, const float* c2, const float* bias, const float* scale,
+                                   const float* shift, float* V, int P, float* slab);
+
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // Where the inputs of one call live: n chunks, chunk c = the tensors of one clip as the caller passed them (SttranInputs'
 // per-clip pointer tables) or ONE chunk = the whole contiguous batch.  All members are DEVICE arrays: the two prefix

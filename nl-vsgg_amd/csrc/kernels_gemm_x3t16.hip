@@ -1,5 +1,5 @@
 // kernels_gemm_x3t16.hip -- the bf16x3 engine on the 128 x 176 / 128 x 128 tiles (gemm_bf16x3_t16.h): instantiation and launch
-#include "gemm_bf16x3_t16.h"
+#include "gemm_bf16x3_t16c.h"
 #include "gemm_launch.h"
 
 namespace sttran {
@@ -86,6 +86,54 @@ hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void
   if (N % 176 == 0) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, e, slab);
   if (N % 128 == 0) return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, e, slab);
   return hipErrorInvalidValue;
+}
+
+// ---- the two convolutions (gemm_bf16x3_t16c.h): activations loaded as fp32 and split in registers, weights fragment-major ----
+template <int AKIND, class Epi>
+static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPlanes& B, int M, int N, int K, const Epi& e, float* slab) {
+  using T = Tile16<128, 128>;
+  static DeviceMarks marks;
+  auto kern = gemm16x3c_kernel<T, AKIND, Epi>;
+  {
+    hipError_t er = marks.raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES);
+    if (er != hipSuccess) return er;
+  }
+  const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles = tm * tn;
+  const int ksteps = K / kBK;
+  const SkPlan sp = sk_plan(TILE_T128x128, tiles, ksteps);
+  const int64_t total = (int64_t)sp.tiles_sk * ksteps;
+  if (total >= (int64_t)1 << 30) return hipErrorInvalidValue;
+  const int base = sp.g_sk ? (int)(total / sp.g_sk) : 0, rem = sp.g_sk ? (int)(total % sp.g_sk) : 0;
+  bool split = false;
+  for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
+  if (split && !slab) return hipErrorInvalidValue;
+  const int half = 2;                              // both N-tiles of an M-panel side by side: the activation rows are read once
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
+                     base, rem, half, slab, e);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess || !split) return err;
+  hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps, sp.g_sk,
+                     base, rem, tiles - sp.tiles_sk, half, slab, e);
+  return hipGetLastError();
+}
+
+// union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]; planes_fm = fragment-major planes of the [256, K] weight
+hipError_t launch_union_conv_x3t16(hipStream_t s, const float* U, const int64_t* u_off, const void* planes_fm, const float* bias,
+                                   float* V, int P, int K, float* slab) {
+  if (K % kBK != 0 || P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16p(planes_fm)) return hipErrorInvalidValue;
+  GemmOperand A{U, (int64_t)K * kUHW, nullptr, P, u_off};
+  const FmPlanes B{reinterpret_cast<const __bf16*>(planes_fm), K / 32, 16};
+  return launch_x3t16c<AC_UNION, EpiUnionRows>(s, A, B, P * kUHW, 256, K, EpiUnionRows{V, bias, 256}, slab);
+}
+
+// Conv2d(128, 256, 3, padding 1) -> ReLU -> BN: planes_fm = planes of the (ky, kx, ci)-ordered [256, 1152] weight, c2 = channel-last
+// [P][7][7][128]
+hipError_t launch_mask_conv2_x3t16(hipStream_t s, const void* planes_fm, const float* c2, const float* bias, const float* scale,
+                                   const float* shift, float* V, int P, float* slab) {
+  if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16p(planes_fm) || !al16p(c2)) return hipErrorInvalidValue;
+  GemmOperand A{c2, 0, nullptr, 0};
+  const FmPlanes B{reinterpret_cast<const __bf16*>(planes_fm), 1152 / 32, 16};
+  return launch_x3t16c<AC_CONV2, EpiConvRows>(s, A, B, P * kUHW, 256, 1152, EpiConvRows{V, bias, scale, shift, 256}, slab);
 }
 
 }  // namespace sttran
