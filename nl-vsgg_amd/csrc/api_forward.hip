@@ -130,7 +130,7 @@ int run_layernorm(SttranHandle* h, hipStream_t s, const float* x, const float* g
   return STTRAN_OK;
 }
 
-int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2) {
+int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2, bool planes_out) {
   const int D = h->cfg.embed_dim, F = h->cfg.ffn_dim;
   const int64_t LD = pad32(D), LF = pad32(F);
   int rb1 = 0, rb2 = 0;
@@ -152,8 +152,19 @@ int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x
       HIPCK(gemm_act_planes_x3t16(s, have ? h->L->hplanes.p : h->L->aplanes.p, w1, rb1, M, F, D, W(h, p + ".linear1.bias"), 1,
                                   h->L->f1planes.p, h->L->slab.as<float>()));
     }
-    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, D, F), gemm_bytes(M, D, F), "gemm16x3_kernel<Tile16<128,176>,EpiLinear>", M, D, F);
-    HIPCK(gemm_linear_x3t16(s, h->L->f1planes.p, w2, rb2, M, D, F, e2, h->L->slab.as<float>()));
+    // planes_out: the output is the next in_proj's activation operand (a decoder layer that is not the last): it leaves as
+    // planes too, into the LayerNorm's plane buffer (whose contents linear1 has consumed; the zero K tail LayerNorm wrote stays)
+    const bool po = planes_out && have && e2.bias && e2.res && !e2.relu && !e2.rowbias && !e2.out_rowidx && !e2.out_rowidx2 &&
+                    !e2.res_rowidx && M <= h->L->hplanes_rows;
+    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(M, D, F), gemm_bytes(M, D, F),
+                 po ? "gemm16x3_kernel<Tile16<128,176>,EpiResPlanes>" : "gemm16x3_kernel<Tile16<128,176>,EpiLinear>", M, D, F);
+    if (po) {
+      HIPCK(gemm_res_planes_x3t16(s, h->L->f1planes.p, w2, rb2, M, D, F, e2, h->L->hplanes.p, h->L->slab.as<float>()));
+      h->L->hplanes_of = e2.C;
+      h->L->hplanes_rows = M;
+    } else {
+      HIPCK(gemm_linear_x3t16(s, h->L->f1planes.p, w2, rb2, M, D, F, e2, h->L->slab.as<float>()));
+    }
     return STTRAN_OK;
   }
   int rc;
@@ -614,7 +625,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       if ((rc = run_layernorm(h, s, Y, W(h, p + ".norm3.weight"), W(h, p + ".norm3.bias"), H, MQ))) return rc;
       EpiLinear e2 = epi_plain(last ? UDEC : G, LD, W(h, p + ".linear2.bias"));
       e2.res = H; e2.ldres = LD;
-      if ((rc = run_ffn(h, s, p, H, F1, MQ, e2))) return rc;
+      if ((rc = run_ffn(h, s, p, H, F1, MQ, e2, !last))) return rc;
     }
   } else if (NT > 0) {
     // dec_layers == 0: windows pass through -- the needed rows are encoder rows

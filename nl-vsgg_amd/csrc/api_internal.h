@@ -236,7 +236,8 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
 // LayerNorm whose output the next GEMM reads: under the bf16x3 engine it also writes that GEMM's activation planes
 int run_layernorm(SttranHandle* h, hipStream_t s, const float* x, const float* gamma, const float* beta, float* y, int M);
 // y = res + linear2(relu(linear1(x))): two run_linear calls, or (bf16x3 engine) planes in, planes between, no split pass
-int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2);
+// planes_out: additionally leave the output as the next GEMM's activation planes (it is an in_proj's input)
+int run_ffn(SttranHandle* h, hipStream_t s, const std::string& p, const float* x, float* f1, int M, EpiLinear e2, bool planes_out = false);
 // ---- api_layout.hip
 int ensure_workspace(SttranHandle* h, int64_t P, int64_t B);
 int upload_staged(SttranHandle* h, hipStream_t s, const void* src, size_t bytes, void* dst);

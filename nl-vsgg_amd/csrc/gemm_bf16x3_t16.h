@@ -107,6 +107,19 @@ struct EpiActPlanes {
   }
 };
 
+// Epilogue of linear2 of a decoder layer whose output the NEXT layer projects (lib/transformer.py:56-58 -> :51): C = acc + bias +
+// residual goes out as the fp32 row the residual path and the gathers need AND as the next in_proj's activation planes.
+struct EpiResPlanes {
+  static constexpr bool kVector = true;
+  float* C; int64_t ldc; const float* bias; const float* res; int64_t ldres; __bf16* planes; int kb_total;
+  __device__ __forceinline__ void vec(int row, int col, f32x4 v) const {
+    v += *reinterpret_cast<const f32x4*>(bias + col);
+    v += *reinterpret_cast<const f32x4*>(res + (int64_t)row * ldres + col);
+    *reinterpret_cast<f32x4*>(C + (int64_t)row * ldc + col) = v;
+    fm_store4(planes, kb_total, row, col, v);
+  }
+};
+
 // T = Tile16<128, 176> or Tile16<128, 128> (gemm_f32_t16.h: only BM, BN, NB, NT are used)
 template <class T>
 struct X3T16 {
@@ -281,6 +294,27 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
           if (r < M) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) epi.vec(r, col0 + 16 * j, acc[i][j]);
+          }
+        }
+      }
+    } else if constexpr (std::is_same<Epi, EpiResPlanes>::value) {
+      if (nsteps == ksteps) {
+        // all loads of a row first (bias + residual), then its stores: a load behind a store waits for the store's
+        // acknowledgement (gemm16_kernel's strip epilogue, same reason)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = row0 + 16 * i;
+          if (r < M) {
+            f32x4 w[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              w[j] = acc[i][j] + *reinterpret_cast<const f32x4*>(epi.bias + col0 + 16 * j) +
+                     *reinterpret_cast<const f32x4*>(epi.res + (int64_t)r * epi.ldres + col0 + 16 * j);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              *reinterpret_cast<f32x4*>(epi.C + (int64_t)r * epi.ldc + col0 + 16 * j) = w[j];
+              fm_store4(epi.planes, epi.kb_total, r, col0 + 16 * j, w[j]);
+            }
           }
         }
       }

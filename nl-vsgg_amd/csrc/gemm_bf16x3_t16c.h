@@ -124,17 +124,24 @@ gemm16x3c_kernel(GemmOperand A, FmPlanes B, int M, int N, int K, int tiles_m, in
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int row0 = m0 + wave * 32 + fr;
     const int col0 = n0 + 4 * fg;
+    // where this lane's two rows live in V[p][c][hw]: &V[p][0][hw] (one division by 49 per row and tile, not per element)
+    float* vrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = row0 + 16 * i < M ? row0 + 16 * i : 0;
+      const int p = r / kUHW;
+      vrow[i] = epi.V + (int64_t)p * epi.C * kUHW + (r - p * kUHW);
+    }
     if constexpr (EpiInit<Epi>::value) {
       // C += A B (EpiUnionRows): the K range that starts a tile accumulates onto the output's old values
       if (ks0 == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int r = row0 + 16 * i;
-          if (r < M) {
+          if (row0 + 16 * i < M) {
 #pragma unroll
             for (int j = 0; j < NB; ++j)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[i][j][e] = epi.init(r, col0 + 16 * j + e);
+              for (int e = 0; e < 4; ++e) acc[i][j][e] = vrow[i][(col0 + 16 * j + e) * kUHW];
           }
         }
       }
@@ -214,12 +221,24 @@ gemm16x3c_kernel(GemmOperand A, FmPlanes B, int M, int N, int K, int tiles_m, in
     // ---- epilogue: row = lane % 16 of block i, columns 4 (lane / 16) + {0..3} of block j; for one register the 16 lanes of a
     //      chunk hold 16 consecutive rows = consecutive hw of one channel: 64-byte runs of V[p][c][hw]
     if (nsteps == ksteps) {
+      // per column group: the per-channel constants as 16-byte loads, shared by the lane's two rows (the functors' vec() loads
+      // them per element: 64 x 1-3 scalar loads per lane and tile, and divides every row by 49)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = row0 + 16 * i;
-        if (r < M) {
+      for (int j = 0; j < NB; ++j) {
+        const int c = col0 + 16 * j;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(epi.bias + c);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (AKIND == AC_CONV2) { sc = *reinterpret_cast<const f32x4*>(epi.scale + c); sh = *reinterpret_cast<const f32x4*>(epi.shift + c); }
 #pragma unroll
-          for (int j = 0; j < NB; ++j) epi.vec(r, col0 + 16 * j, acc[i][j]);
+        for (int i = 0; i < 2; ++i) {
+          if (row0 + 16 * i < M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[i][j][e] + b[e];
+              if constexpr (AKIND == AC_CONV2) v = relu_nan(v) * sc[e] + sh[e];      // ReLU, then the eval-mode BN (lib/sttran.py:343-344)
+              vrow[i][(c + e) * kUHW] = v;
+            }
+          }
         }
       }
     } else {

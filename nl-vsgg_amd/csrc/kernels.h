@@ -100,6 +100,10 @@ hipError_t gemm_linear_x3t16(hipStream_t s, const void* a_planes, const void* b_
 hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
                                  const float* bias, int relu, void* out_planes, float* slab);
 
+// C = A W^T + bias + residual as fp32 rows AND as fragment-major planes [M, N] (N's tail to the next multiple of 32 is NOT
+// written: the caller's buffer must hold zeros there -- hplanes does, LayerNorm writes that tail on every pass)
+hipError_t gemm_res_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                                 const EpiLinear& epi, void* out_planes, float* slab);
 // the two convolutions on the same engine (gemm_bf16x3_t16c.h): planes_fm = fragment-major planes (split_fm, weight = 1) of the
 // [256, K] / [256, 1152] weight
 hipError_t launch_union_conv_x3t16(hipStream_t s, const float* U, const int64_t* u_off, const void* planes_fm, const float* bias,

@@ -88,6 +88,21 @@ hipError_t gemm_act_planes_x3t16(hipStream_t s, const void* a_planes, const void
   return hipErrorInvalidValue;
 }
 
+// C = A W^T + bias + res as fp32 rows AND as the next launch's activation planes (linear2 of a decoder layer that is not the last)
+hipError_t gemm_res_planes_x3t16(hipStream_t s, const void* a_planes, const void* b_planes, int b_row_blocks, int M, int N, int K,
+                                 const EpiLinear& epi, void* out_planes, float* slab) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if (!epi.bias || !epi.res || epi.relu || epi.rowbias || epi.out_rowidx || epi.out_rowidx2 || epi.scale || epi.res_rowidx ||
+      !x3t16_tile(N, epi) || !al16p(out_planes) || b_row_blocks * 16 < N)
+    return hipErrorInvalidValue;
+  const int kb = (K + 31) / 32;
+  const FmPlanes A{reinterpret_cast<const __bf16*>(a_planes), kb, (M + 15) / 16};
+  const FmPlanes B{reinterpret_cast<const __bf16*>(b_planes), kb, b_row_blocks};
+  const EpiResPlanes e{epi.C, epi.ldc, epi.bias, epi.res, epi.ldres, reinterpret_cast<__bf16*>(out_planes), (N + 31) / 32};
+  if (N % 176 == 0) return launch_x3t16<Tile16<128, 176>, TILE_128x176>(s, A, B, M, N, K, e, slab);
+  return launch_x3t16<Tile16<128, 128>, TILE_T128x128>(s, A, B, M, N, K, e, slab);
+}
+
 // ---- the two convolutions (gemm_bf16x3_t16c.h): activations loaded as fp32 and split in registers, weights fragment-major ----
 template <int AKIND, class Epi>
 static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPlanes& B, int M, int N, int K, const Epi& e, float* slab) {
