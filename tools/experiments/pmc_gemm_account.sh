@@ -7,7 +7,8 @@ P=${1:?prefix}; C=${2:?commit}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-SHAPES="21120,1936,1936,5,1 10560,1936,1936,5,1 21120,5808,1936,5,0 10560,5808,1936,5,0 21120,2048,1936,7,0 11264,512,12544,7,0"
+SHAPES=${SHAPES:-"21120,1936,1936,5,1 10560,1936,1936,5,1 21120,5808,1936,5,0 10560,5808,1936,5,0 21120,2048,1936,7,0 11264,512,12544,7,0"}
+export SHAPES
 for sh in $SHAPES; do
   IFS=, read M N K T R <<< "$sh"
   res=""; [ "$R" = 1 ] && res="--residual"
@@ -22,7 +23,8 @@ import glob, json, sys
 import pandas as pd
 P, C = sys.argv[1], sys.argv[2]
 rows = []
-for sh in "21120,1936,1936,5,1 10560,1936,1936,5,1 21120,5808,1936,5,0 10560,5808,1936,5,0 21120,2048,1936,7,0 11264,512,12544,7,0".split():
+import os
+for sh in os.environ["SHAPES"].split():
     M, N, K, T, R = (int(v) for v in sh.split(","))
     rec = {"M": M, "N": N, "K": K, "tile": {5: "128x176", 7: "128x128 (16x16x4)"}[T], "residual": bool(R)}
     for c in ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]:

@@ -30,6 +30,7 @@ kt single --clips-per-step 1 --steps 50 --warmup 3
 kt single_64x36 --workload 64x36 --clips-per-step 1 --steps 20 --warmup 3
 kt dsgdetr_16x12 --model dsgdetr --steps 10 --warmup 3
 kt dsgdetr_64x36 --model dsgdetr --workload 64x36 --steps 10 --warmup 3
+kt 16x12_bf16x3 --workload 16x12 --gemm-engine bf16x3 --steps 20 --warmup 3       # the second engine (opt-in; never `value`)
 # 2. fabric traffic of the GEMM class (FETCH_SIZE x 2 per the gfx950 note, WRITE_SIZE), STTran and DSG-DETR
 for w in 16x12 64x36; do
   for c in FETCH_SIZE WRITE_SIZE; do pmc "$w" $c --workload $w --steps 3 --warmup 1; done
@@ -47,6 +48,10 @@ done
 # ... and of every kernel class of the step side by side, the non-GEMM kernels included (round 5)
 python3 tools/pmc_kernels.py "$O/${P}_pmc_busy_" "$C" mask_conv1_pool_kernel attention_short_kernel layernorm_kernel EpiUnionT16 EpiConvT16 \
   "Tile16<128, 176>" "Tile16<128, 128>" > "$O/${P}_pmc_kernels.json"
+# ... and of the second engine's kernels (round 6: gemm16x3_kernel / gemm16x3c_kernel / split_fm_kernel)
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU; do pmc busyx3 $c --gemm-engine bf16x3 --steps 3 --warmup 1; done
+python3 tools/pmc_kernels.py "$O/${P}_pmc_busyx3_" "$C" "gemm16x3_kernel<sttran::Tile16<128, 176>" "gemm16x3_kernel<sttran::Tile16<128, 128>" \
+  "gemm16x3c_kernel" "split_fm_kernel" "gemm_x3_kernel" "layernorm_kernel" > "$O/${P}_x3_pmc.json"
 # 4. bench lines (unprofiled)
 # (stdout = the one compact line the driver parses; the full object goes to $BENCH_DETAIL)
 BENCH_DETAIL="$O/${P}_bench_default_detail.json" python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
@@ -64,6 +69,11 @@ python3 bench.py --gpus 1 --rccl-selftest > "$O/${P}_rccl_selftest.json" 2> "$O/
 # two ranks on this one GPU over gloo (the N > 1 code path, self-launched): what the 8-GPU driver run will execute
 BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline \
   --detail "$O/${P}_bench_2ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_2ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_2ranks.err" || true
+# ... and eight ranks the same way: the dry run of the driver's one 8-GPU shot (record shape, gather, LPT, merged recall)
+BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --clips-per-step 8 \
+  --strong-clips 16 --ag-clips 256 --detail "$O/${P}_bench_8ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_8ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_8ranks.err" || true
+# the second engine alone on its shapes (kernel on pre-split operands, split pass, round 2's kernel, the exact engine)
+python3 tools/x3_bench.py --shapes path16x64 > "$O/${P}_x3_bench.txt" 2>/dev/null || true
 # raw rocprofv3 output is scratch: only the summaries travel back (gpurun merges at most 64 MiB)
 rm -rf "$O/${P}"_kt_*/ "$O/${P}"_pmc_*_[A-Z]*/
 find "$O" -maxdepth 1 -name "${P}_pmc_*_[A-Z]*.err" -size -1k -delete
