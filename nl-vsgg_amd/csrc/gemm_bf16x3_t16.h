@@ -130,7 +130,13 @@ struct X3T16 {
   static constexpr int CPW = (CHUNKS + 3) / 4;             // ... per wave (the last wave(s) have one less)
 };
 
-template <class T, class Epi>
+// ABL: timing-only ablations for tools/x3_bench.py (experiment builds, wrong results): 1 = no epilogue stores, 2 = no barrier in
+// the K loop, 3 = no LDS-DMA in the loop (the weight stage is never refilled), 4 = no A-fragment loads in the loop, 5 = 3 + 4,
+// 6 = every load of the loop issued but from ONE small footprint (row blocks 0..7, column blocks 0..10, K block 0: always an L2
+// hit) -- separates the cost of the load path from the cost of the misses.  (Round 6, one box: [21120,1936,1936] 838 us; no
+// epilogue stores 811; no barrier 830; no LDS-DMA 762; no A loads 687; neither 592; all loads but always hits 741.  Non-temporal
+// hints on the A loads / the LDS-DMA / both: 862 / 931 / 993 us -- the caches DO serve neighbours; removed again.)
+template <class T, class Epi, int ABL = 0>
 __global__ void __launch_bounds__(T::NT, 2)
 gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg, int g_sk,
                 int sk_base, int sk_rem, int half, float* __restrict__ slab, Epi epi) {
@@ -176,10 +182,10 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     const char* a_base[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int rb = min(m0 / 16 + 2 * wave + i, A.rb_total - 1);
-      a_base[i] = reinterpret_cast<const char*>(A.ptr) + ((int64_t)rb * A.kb_total + ks0) * (kFmBlock3 * 2);
+      const int rb = ABL == 6 ? 2 * wave + i : min(m0 / 16 + 2 * wave + i, A.rb_total - 1);
+      a_base[i] = reinterpret_cast<const char*>(A.ptr) + ((int64_t)rb * A.kb_total + (ABL == 6 ? 0 : ks0)) * (kFmBlock3 * 2);
     }
-    const char* const b_base = reinterpret_cast<const char*>(B.ptr) + ((int64_t)(n0 / 16) * B.kb_total + ks0) * (kFmBlock3 * 2);
+    const char* const b_base = reinterpret_cast<const char*>(B.ptr) + ((int64_t)(ABL == 6 ? 0 : n0 / 16) * B.kb_total + (ABL == 6 ? 0 : ks0)) * (kFmBlock3 * 2);
     const int64_t b_cb = (int64_t)B.kb_total * (kFmBlock3 * 2);        // bytes between column blocks
     // LDS-DMA piece q of this wave: chunk c = wave + 4 q of the stage image [NB][3][1 KB] = (column block c / 3, plane c % 3)
     // (33 chunks over 4 waves x 9 pieces: the three pieces past the end re-stage the last chunk -- same bytes to the same
@@ -187,7 +193,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     //  every piece the fragment reads of block j + 1 were issued, and waited for, in FRONT of block j's MFMAs)
     auto glds_piece = [&](int q, int step, unsigned char* stage) {
       const int c = min(wave + 4 * q, X::CHUNKS - 1);
-      const char* src = b_base + (c / 3) * b_cb + (int64_t)step * (kFmBlock3 * 2) + (c % 3) * 1024;
+      const char* src = b_base + (c / 3) * b_cb + (int64_t)(ABL == 6 ? 0 : step) * (kFmBlock3 * 2) + (c % 3) * 1024;
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lane_b),
                                        (void __attribute__((address_space(3)))*)(stage + c * 1024), 16, 0, 0);
     };
@@ -197,7 +203,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     };
     bf16x8 fa[2][3][2];                                             // [set][plane][row block]
     auto load_a1 = [&](int set, int step, int i, int pl) {
-      fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(a_base[i] + (int64_t)step * (kFmBlock3 * 2) + pl * 1024 + lane_a);
+      fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(a_base[i] + (int64_t)(ABL == 6 ? 0 : step) * (kFmBlock3 * 2) + pl * 1024 + lane_a);
     };
     auto load_a = [&](int set, int step) {
 #pragma unroll
@@ -229,8 +235,8 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     // one memory piece of the NEXT K-step: pieces 0 .. CPW-1 = this wave's LDS-DMA chunks, CPW .. CPW+5 = its A fragments
     constexpr int NVM = X::CPW + 6;
     auto vmem_piece = [&](int n, int set_next, int step, unsigned char* stage) {
-      if (n < X::CPW) glds_piece(n, step, stage);
-      else if (n < NVM) load_a1(set_next, step, (n - X::CPW) / 3, (n - X::CPW) % 3);
+      if (n < X::CPW) { if constexpr (ABL != 3 && ABL != 5) glds_piece(n, step, stage); }
+      else if (n < NVM) { if constexpr (ABL != 4 && ABL != 5) load_a1(set_next, step, (n - X::CPW) / 3, (n - X::CPW) % 3); }
     };
 
     stage_b(0, smem_x3);
@@ -267,7 +273,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
         __builtin_amdgcn_sched_barrier(0);
       }
       static_assert(2 * (NB - 1) >= NVM, "the next K-step's memory pieces must fit the blocks in front of the held-over one");
-      __syncthreads();                            // every wave has read `cur`; `nxt` and the next A fragments have landed
+      if constexpr (ABL != 2) __syncthreads();    // every wave has read `cur`; `nxt` and the next A fragments have landed
       read_b(nxt, 0, (par + NB) & 1);
       __builtin_amdgcn_sched_barrier(0);          // issue these reads BEFORE the held-over block, which then hides them
       mma_block(set, NB - 1, (par + NB - 1) & 1);
@@ -286,6 +292,9 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     // ---- epilogue: gemm16_kernel's (same accumulator layout: row = lane % 16 of block i, columns 4 (lane / 16) + {0..3} of block j)
     const int row0 = m0 + wave * 32 + fr;
     const int col0 = n0 + 4 * fg;
+    if constexpr (ABL == 1) {
+      if (acc[0][0][0] == 12345.678f) slab[tid] = acc[1][NB - 1][3];      // keep the accumulators alive; never true
+    } else
     if constexpr (std::is_same<Epi, EpiActPlanes>::value) {
       if (nsteps == ksteps) {
 #pragma unroll

@@ -24,8 +24,21 @@ static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes&
                                float* slab) {
   static DeviceMarks marks;
   auto kern = gemm16x3_kernel<T, Epi>;
+#ifdef STTRAN_GEMM_EXPERIMENT
   {
-    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES);
+    static DeviceMarks m[7];
+    const int abl = getenv("STTRAN_X3_ABLATE") ? atoi(getenv("STTRAN_X3_ABLATE")) : 0;
+    if (abl == 1) kern = gemm16x3_kernel<T, Epi, 1>;
+    if (abl == 2) kern = gemm16x3_kernel<T, Epi, 2>;
+    if (abl == 3) kern = gemm16x3_kernel<T, Epi, 3>;
+    if (abl == 4) kern = gemm16x3_kernel<T, Epi, 4>;
+    if (abl == 5) kern = gemm16x3_kernel<T, Epi, 5>;
+    if (abl == 6) kern = gemm16x3_kernel<T, Epi, 6>;
+    if (abl >= 1 && abl <= 6 && m[abl].raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES) != hipSuccess) return hipErrorUnknown;
+  }
+#endif
+  {
+    hipError_t e = marks.raise_lds(reinterpret_cast<const void*>(gemm16x3_kernel<T, Epi>), X3T16<T>::LDS_BYTES);
     if (e != hipSuccess) return e;
   }
   const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles = tm * tn;
@@ -37,7 +50,9 @@ static hipError_t launch_x3t16(hipStream_t s, const FmPlanes& A, const FmPlanes&
   bool split = false;
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
-  const int half = T::GROUP_N;
+  // N-tiles per group of the tile order (see launch_t16); experiment builds: STTRAN_X3_GROUP_N
+  static const int env_gn = exp_env("STTRAN_X3_GROUP_N") ? atoi(exp_env("STTRAN_X3_GROUP_N")) : 0;
+  const int half = env_gn > 0 ? env_gn : T::GROUP_N;
   hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
                      base, rem, half, slab, e);
   hipError_t err = hipGetLastError();
