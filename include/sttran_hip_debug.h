@@ -12,12 +12,15 @@
 extern "C" {
 #endif
 
-/* GEMM engine of the nn.Linear layers and the two convolutions (no reference counterpart).  STTRAN_GEMM_FP32_MFMA (default): exact fp32 on
- * v_mfma_f32_32x32x2_f32.  STTRAN_GEMM_BF16X3 (EXPERIMENT, opt-in): fp32 EMULATED on the bf16 matrix pipe -- every
- * operand split into three bf16 planes, six cross products per element pair on v_mfma_f32_32x32x16_bf16, fp32
- * accumulation (csrc/gemm_bf16x3.h); measured error against fp64 no larger than the exact engine's.  The weights are
- * split once (at the next forward); activations are split on the fly.  Attention, the 7x7 mask convolution and the
- * small GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
+/* GEMM engine of the nn.Linear layers and the two convolutions (no reference counterpart; SURVEY.md 7 names both: "fp32 MFMA ...
+ * or 3 x bf16 split").  STTRAN_GEMM_FP32_MFMA (default): exact fp32 on v_mfma_f32_16x16x4_f32 / 32x32x2_f32.
+ * STTRAN_GEMM_BF16X3 (opt-in second engine): fp32 EMULATED on the bf16 matrix pipe -- every operand split into three bf16
+ * planes, six cross products per element pair, fp32 accumulation; measured error against fp64 no larger than the exact
+ * engine's.  Since round 6 on v_mfma_f32_16x16x32_bf16 with both operands as pre-split fragment-major planes
+ * (csrc/gemm_bf16x3_t16.h, gemm_bf16x3_t16c.h): weights are split once (at the next forward), activations by their producer
+ * (LayerNorm, the linear1 / linear2 epilogues) or by one split pass; the launches those tiles do not serve (vr_fc, the grouped
+ * subj | obj FC) run on round 2's kernel (csrc/gemm_bf16x3.h, activations split by the A loader).  Attention, the 7x7 mask
+ * convolution and the small GEMMs (fewer than 512 rows, or N < 128) stay on the exact engine. */
 /* STTRAN_GEMM_BF16X3_ALL: the emulated engine for EVERY contraction it can take (N >= 128), whatever the row count -- the
  * form the parity tests use so that small fixtures exercise it too (BF16X3 keeps launches under 512 rows on the exact engine,
  * where the 256-row emulation tile would mostly compute padding). */
