@@ -67,12 +67,13 @@ struct Tile16 {
 // ROWOFF (round 4; the 128 x 128 tile only -- it has the registers): the A rows are gathered by 64-bit ELEMENT offsets
 // (GemmOperand::rowoff: the feature rows of a batch handed over as per-clip pointer tables live in several allocations),
 // one 64-bit pointer per staged piece instead of a 32-bit offset; GemmOperand::aux = the column split of a grouped launch.
-// GANG (round 6; the N = 512 launch of vr_fc, K = 12 544): `half` workgroups with consecutive ids form a gang that walks ONE
-// stream-K range over (M-panel, K-step) in lockstep, workgroup g of the gang on N-tile g -- the gang's members read the same
-// rows of A at the same time (they sit on one XCD: xcd_remap), so the activation panel crosses the fabric once instead of
-// once per N-tile.  (Plain stream-K gives every workgroup its own range: the four N-tiles of a panel are then computed at
-// unrelated K offsets and `V` was read 4 x, L2 hit rate 4 %: profiles/r5_f_gemm_traffic_account.json.)  No whole tiles in
-// this mode (dp_per_wg = 0); g_sk / sk_base / sk_rem count GANGS.
+// GANG (round 6; the N = 512 launch of vr_fc, K = 12 544): `dp_per_wg` (= GM, re-used: there are no whole tiles in this mode)
+// x `half` (= the N-tiles) workgroups with consecutive ids form a gang that walks ONE stream-K range over (group of GM
+// M-panels, K-step) in lockstep, member j on panel j / half of the group and N-tile j % half -- the members read the same
+// rows of A (those on one panel) and the same rows of W (those on one N-tile) at the same time, on one XCD (xcd_remap), so an
+// activation panel crosses the fabric once instead of once per N-tile and a weight panel once per GM M-panels.  (Plain
+// stream-K gives every workgroup its own range: the four N-tiles of a panel are then computed at unrelated K offsets and
+// `V` was read 4 x, L2 hit rate 4 %: profiles/r5_f_gemm_traffic_account.json.)  g_sk / sk_base / sk_rem count GANGS.
 template <class T, class Epi, int ABL = 0, bool ROWOFF = false, bool GANG = false>
 __global__ void __launch_bounds__(T::NT, 2)
 gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
@@ -99,8 +100,12 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
 
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);
+  const int gang_gm = GANG ? dp_per_wg : 1;                 // M-panels per gang (GANG re-uses the argument)
+  if constexpr (GANG) dp_per_wg = 0;
   const int tiles_dp = dp_per_wg * G;
-  const int gang_id = GANG ? blk / half : blk, gang_n = GANG ? blk - gang_id * half : 0;
+  const int gang_sz = GANG ? gang_gm * half : 1;
+  const int gang_id = GANG ? blk / gang_sz : blk, gang_j = GANG ? blk - gang_id * gang_sz : 0;
+  const int gang_n = GANG ? gang_j % half : 0, gang_m = GANG ? gang_j / half : 0;
   const SkRange rg = gang_id < g_sk ? sk_range(gang_id, sk_base, sk_rem) : SkRange{0, 0};
   // Every workgroup runs its whole tiles first and its stream-K range last, in step with its neighbours: the 64
   // workgroups of an XCD then work on one compact block of tiles at any moment and share its operand panels through that
@@ -132,8 +137,10 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
     }
     const int nsteps = ks1 - ks0;
     int tile_m, tile_n;
-    if constexpr (GANG) { tile_m = tile; tile_n = gang_n; }                   // the range runs over M-panels; this member's N-tile
-    else tile_origin_rt(tile, tiles_m, tiles / tiles_m, half, tile_m, tile_n);     // `half` = N-tiles per group of the tile order
+    if constexpr (GANG) {                                       // the range runs over groups of GM panels; this member's tile
+      tile_m = tile * gang_gm + gang_m; tile_n = gang_n;
+      if (tile_m >= tiles_m) { it += nsteps; continue; }      // (an odd panel count: the last group's upper members idle)
+    } else tile_origin_rt(tile, tiles_m, tiles / tiles_m, half, tile_m, tile_n);     // `half` = N-tiles per group of the tile order
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #ifdef STTRAN_GEMM_EXPERIMENT
     unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
@@ -397,15 +404,19 @@ gemm16_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, in
 }
 
 // grid = (stream-K tiles, 2 * NB): one workgroup per accumulator register group of a split tile
-// GANG: blockIdx.x = panel * group_n + N-tile; the owners are gangs, gang b's member for this N-tile parked at slab block
-// b * group_n + N-tile
+// GANG: blockIdx.x = panel * group_n + N-tile, tiles_dp = GM (panels per gang; re-used); the owners are gangs: gang b's member
+// for (panel % GM, N-tile) parked at slab block b * GM * group_n + (panel % GM) * group_n + N-tile
 template <class T, class Epi, bool GANG = false>
 __global__ void __launch_bounds__(T::NT)
 gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk, int sk_base, int sk_rem, int tiles_dp,
                     int group_n, const float* __restrict__ slab, Epi epi) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB;
+  const int gang_gm = GANG ? tiles_dp : 1;
+  if constexpr (GANG) tiles_dp = 0;
   const int gang_n = GANG ? (int)blockIdx.x % group_n : 0;
-  const int tile = GANG ? (int)blockIdx.x / group_n : (int)blockIdx.x;
+  const int panel = GANG ? (int)blockIdx.x / group_n : 0;
+  const int tile = GANG ? panel / gang_gm : (int)blockIdx.x;          // GANG: the group of panels the owners' ranges run over
+  const int gang_j = GANG ? (panel - tile * gang_gm) * group_n + gang_n : 0;
   const int t0 = tile * ksteps, t1 = t0 + ksteps;
   const int b_lo = sk_owner(t0, sk_base, sk_rem), b_hi = sk_owner(t1 - 1, sk_base, sk_rem);
   if (b_lo == b_hi) return;                      // computed whole by one workgroup: nothing parked
@@ -420,7 +431,7 @@ gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk
       const int bb = b + u;
       const bool ok = bb <= b_hi;
       const int slot = (bb == b_lo && sk_range(bb, sk_base, sk_rem).begin < t0) ? 1 : 0;
-      const int64_t sb = GANG ? (int64_t)(ok ? bb : b_lo) * group_n + gang_n : (int64_t)(ok ? bb : b_lo);
+      const int64_t sb = GANG ? (int64_t)(ok ? bb : b_lo) * (gang_gm * group_n) + gang_j : (int64_t)(ok ? bb : b_lo);
       const f32x4* sp = base + (sb * 2 + slot) * (BM * BN / 4);
       v[u] = ok ? *sp : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -429,7 +440,7 @@ gemm16_fixup_kernel(int M, int N, int tiles_m, int tiles_n, int ksteps, int g_sk
   }
   const int gt = tiles_dp + tile;
   int tile_m, tile_n;
-  if constexpr (GANG) { tile_m = tile; tile_n = gang_n; }
+  if constexpr (GANG) { tile_m = panel; tile_n = gang_n; }
   else tile_origin_rt(gt, tiles_m, tiles_n, group_n, tile_m, tile_n);
   const int row = tile_m * BM + wave * 32 + 16 * i + fr;
   const int col = tile_n * BN + 16 * j + 4 * fg;

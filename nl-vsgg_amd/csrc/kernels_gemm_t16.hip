@@ -62,7 +62,11 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
     // stream-K range over (M-panel, K-step) in lockstep, so an A panel is read once, not once per N-tile (gemm16_kernel GANG)
     const int Gw = num_cus() * kTiles[TILE_ID].blocks_per_cu;
     static const int env_gang = exp_env("STTRAN_T16_GANG") ? atoi(exp_env("STTRAN_T16_GANG")) : 1;
-    if (env_gang && tn >= 2 && tn <= 8 && Gw % tn == 0 && ksteps >= 128 && tiles < 2 * Gw && (int64_t)tm * ksteps >= (int64_t)(Gw / tn) * 8) {
+    // GM = 2 M-panels per gang when that divides the grid: the members on one N-tile then share their weight panel too
+    const int gm = (env_gang >= 2 ? env_gang - 1 : 2);
+    const int GMv = (tm >= 2 && Gw % (tn * gm) == 0) ? gm : 1;
+    if (env_gang && tn >= 2 && tn <= 8 && Gw % (tn * GMv) == 0 && ksteps >= 128 && tiles < 2 * Gw &&
+        (int64_t)((tm + GMv - 1) / GMv) * ksteps >= (int64_t)(Gw / (tn * GMv)) * 8) {
 #ifdef STTRAN_GEMM_EXPERIMENT
       if (getenv("STTRAN_T16_ABLATE") && atoi(getenv("STTRAN_T16_ABLATE")) != 0) goto plain;
 #endif
@@ -71,16 +75,16 @@ static hipError_t launch_t16(hipStream_t s, const GemmOperand& A, const GemmOper
         auto gk = gemm16_kernel<T, Epi, 0, false, true>;
         hipError_t e0 = gmarks.raise_lds(reinterpret_cast<const void*>(gk), T::LDS_BYTES);
         if (e0 != hipSuccess) return e0;
-        const int gangs = Gw / tn;
-        const int64_t total = (int64_t)tm * ksteps;
+        const int gangs = Gw / (tn * GMv);
+        const int64_t total = (int64_t)((tm + GMv - 1) / GMv) * ksteps;      // (group of GM panels, K-step)
         if (total >= (int64_t)1 << 30 || !slab) return hipErrorInvalidValue;
         const int base = (int)(total / gangs), rem = (int)(total % gangs);
         const Epi e{epi};
-        hipLaunchKernelGGL(gk, dim3(Gw), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, 0, gangs, base, rem, tn, slab, e);
+        hipLaunchKernelGGL(gk, dim3(Gw), dim3(T::NT), T::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, GMv, gangs, base, rem, tn, slab, e);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
         hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi, true>), dim3(tm * tn, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps, gangs,
-                           base, rem, 0, tn, slab, e);
+                           base, rem, GMv, tn, slab, e);
         return hipGetLastError();
       }
     }

@@ -268,7 +268,19 @@ def run_workspace():
     from nl_vsgg_amd.lib.dsg_detr import STTran as DSG
     from nl_vsgg_amd.lib.sttran import pack_clips
     keys = ("attention_distribution", "spatial_distribution", "contacting_distribution")
-    h = hashlib.sha256()
+
+    class _H:
+        """sha256 of everything + a short per-case line on stderr (which case differs, when the parent's comparison fails)"""
+        def __init__(self):
+            self.all, self.case, self.n = hashlib.sha256(), hashlib.sha256(), 0
+        def update(self, b):
+            self.all.update(b); self.case.update(b)
+        def mark(self, what):
+            print("case %d %s %s" % (self.n, what, self.case.hexdigest()[:16]), file=sys.stderr)
+            self.case, self.n = hashlib.sha256(), self.n + 1
+        def hexdigest(self):
+            return self.all.hexdigest()
+    h = _H()
     sd = syn.make_sttran_state_dict(7)
     for mode in ("predcls", "sgdet"):
         m = _model(mode, sd)
@@ -281,6 +293,7 @@ def run_workspace():
             m.sync_check()
             for k in keys:
                 h.update(out[k].cpu().numpy().tobytes())
+            h.mark("%s %d frames" % (mode, len(counts)))
             if len(counts) < 64:
                 clips.append(e)
         m2 = _model(mode, sd)                                  # a fresh handle: its workspace is sized by THIS call exactly
@@ -288,12 +301,14 @@ def run_workspace():
         m2.sync_check()
         for k in keys:
             h.update(out[k].cpu().numpy().tobytes())
+        h.mark(mode + " by-pointer batch")
         if mode == "predcls":
             m2.gemm_engine = "bf16x3_all"
             out = m2(dict(clips[1]))
             m2.sync_check()
             for k in keys:
                 h.update(out[k].cpu().numpy().tobytes())
+            h.mark("bf16x3_all")
     d = DSG(mode="sgdet", attention_class_num=3, spatial_class_num=6, contact_class_num=17, obj_classes=CLASSES).to("cuda:0")
     d.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in syn.make_dsg_detr_state_dict(7).items()}, strict=False)
     for seed, counts in ((333, [35] * 20), (334, [3, 0, 4, 1]), (335, [11] * 16)):
@@ -303,6 +318,7 @@ def run_workspace():
         torch.cuda.synchronize()
         for k in keys:
             h.update(out[k].cpu().numpy().tobytes())
+        h.mark("dsgdetr %d" % seed)
     print("OK workspace SUM " + h.hexdigest())
 
 

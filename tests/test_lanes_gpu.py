@@ -210,9 +210,11 @@ def test_second_engine_on_lanes_and_engine_switches(weights, coalesce):
         for e in entries:
             pending.append(m.forward_async(_cuda_entry(e)))
             if len(pending) == m.pipeline_depth:
-                got.append({k: m.join(pending.popleft())[k].clone() for k in OUT_KEYS})
+                p = m.join(pending.popleft())
+                got.append({k: p[k].clone() for k in OUT_KEYS})
     while pending:
-        got.append({k: m.join(pending.popleft())[k].clone() for k in OUT_KEYS})
+        p = m.join(pending.popleft())
+        got.append({k: p[k].clone() for k in OUT_KEYS})
     m.sync_check()
     assert len(got) == 2 * len(entries)
     for i, g in enumerate(got):
