@@ -72,6 +72,11 @@ BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 2 --steps 5
 # ... and eight ranks the same way: the dry run of the driver's one 8-GPU shot (record shape, gather, LPT, merged recall)
 BENCH_DIST_BACKEND=gloo BENCH_FORCE_DEVICE=0 python3 bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --clips-per-step 8 \
   --strong-clips 16 --ag-clips 256 --detail "$O/${P}_bench_8ranks_gloo_one_gpu_detail.json" > "$O/${P}_bench_8ranks_gloo_one_gpu.json" 2> "$O/${P}_bench_8ranks.err" || true
+# RCCL / gloo print banners on stdout ahead of the line: the committed files keep the line only
+for f in rccl_selftest bench_2ranks_gloo_one_gpu bench_8ranks_gloo_one_gpu; do
+  grep '^{' "$O/${P}_$f.json" > "$O/${P}_$f.json.tmp" || true
+  mv "$O/${P}_$f.json.tmp" "$O/${P}_$f.json"
+done
 # the second engine alone on its shapes (kernel on pre-split operands, split pass, round 2's kernel, the exact engine)
 python3 tools/x3_bench.py --shapes path16x64 > "$O/${P}_x3_bench.txt" 2>/dev/null || true
 # raw rocprofv3 output is scratch: only the summaries travel back (gpurun merges at most 64 MiB)
