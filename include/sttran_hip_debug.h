@@ -62,6 +62,10 @@ int sttran_debug_mfma_peak(int32_t iters, double* tflops);
  * `cookie` goes to sttran_debug_guarded_free.  STTRAN_ERR_HIP if the driver has no virtual-memory API. */
 int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie);
 int sttran_debug_guarded_free(void* cookie);
+/* on != 0: sttran_debug_guarded_free hands the address range back too (hipMemAddressFree).  Off by default: a range that is
+ * reserved again and mapped to new memory can be reached through its old translation on this driver
+ * (tools/experiments/vmm_reuse_probe.py is the only caller). */
+int sttran_debug_guarded_return_addresses(int32_t on);
 /* The tile id (1..8, see csrc/kernels.h) the planner picks for an [M,N,K] nn.Linear GEMM on the current device. */
 int sttran_debug_plan_tile(int64_t M, int64_t N, int64_t K);
 /* y[r,:] = LayerNorm(x[r,:]) * gamma + beta, eps 1e-5 (lib/transformer.py:15-16). */

@@ -143,6 +143,7 @@ SYMBOLS = [
     ("sttran_debug_plan_tile", C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     ("sttran_debug_guarded_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("sttran_debug_guarded_free", C.c_int, [C.c_void_p]),
+    ("sttran_debug_guarded_return_addresses", C.c_int, [C.c_int32]),
     ("sttran_debug_mask_conv1_pool", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                C.c_void_p]),
     ("sttran_debug_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,

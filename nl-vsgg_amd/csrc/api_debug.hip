@@ -200,6 +200,8 @@ int sttran_debug_guarded_alloc(size_t bytes, void** ptr, void** cookie) {
   *cookie = g;
   return STTRAN_OK;
 }
+static bool g_guard_return_addresses = false;
+int sttran_debug_guarded_return_addresses(int32_t on) { g_guard_return_addresses = on != 0; return STTRAN_OK; }
 int sttran_debug_guarded_free(void* cookie) {
   if (!cookie) return STTRAN_ERR_INVALID;
   auto* g = static_cast<GuardedAlloc*>(cookie);
@@ -211,6 +213,7 @@ int sttran_debug_guarded_free(void* cookie) {
   // shows hipMemcpy reading stale data behind a torch kernel with none of this library's kernels involved, and the zero
   // fill of a regrown workspace buffer landed in another live buffer (round 6: one wrong bf16x3_all forward in eight under
   // STTRAN_GUARD_WORKSPACE=1, never without).  A test allocator can afford to leak address space.
+  if (g_guard_return_addresses) hipMemAddressFree(g->base, g->reserved);      // the probe's switch: the old behaviour
   delete g;
   return STTRAN_OK;
 }
