@@ -26,7 +26,7 @@ rows = []
 import os
 for sh in os.environ["SHAPES"].split():
     M, N, K, T, R = (int(v) for v in sh.split(","))
-    rec = {"M": M, "N": N, "K": K, "tile": {5: "128x176", 7: "128x128 (16x16x4)"}[T], "residual": bool(R)}
+    rec = {"M": M, "N": N, "K": K, "tile": {0: "planner's choice", 5: "128x176", 7: "128x128 (16x16x4)"}.get(T, str(T)), "residual": bool(R)}
     for c in ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]:
         fs = glob.glob(f"gpurun_out/{P}_acct_{M}_{N}_{K}_{c}/*/*counter_collection.csv")
         if not fs:
