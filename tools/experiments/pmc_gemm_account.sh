@@ -35,7 +35,7 @@ for sh in os.environ["SHAPES"].split():
         t = t[(t["Counter_Name"] == c) & t["Kernel_Name"].str.contains("gemm16_kernel") & ~t["Kernel_Name"].str.contains("fixup")]
         if len(t):
             rec[c] = float(t["Counter_Value"].tail(3).mean())
-    tfl = [l for l in open(f"gpurun_out/{P}_acct_{M}_{N}_{K}_FETCH_SIZE.out").read().splitlines() if "TFLOP" in l and "device" not in l]
+    tfl = [l for l in open(f"gpurun_out/{P}_acct_{M}_{N}_{K}_FETCH_SIZE.out").read().splitlines() if " TF" in l and "auto[" in l]
     rec["bench_line"] = tfl[-1].strip() if tfl else None
     a, w, c_ = M * K * 4, N * K * 4, M * N * 4
     rec["algorithmic_read_bytes"] = a + w + (c_ if R else 0)
