@@ -234,6 +234,14 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     };
     // one memory piece of the NEXT K-step: pieces 0 .. CPW-1 = this wave's LDS-DMA chunks, CPW .. CPW+5 = its A fragments
     constexpr int NVM = X::CPW + 6;
+#ifndef X3_PPB
+#define X3_PPB 4
+#endif
+    // memory pieces per block: 4 puts the 15 (128 columns: 12) pieces of a step into its first 4 (3) blocks, so the last one is
+    // issued 6 (4) blocks in front of the barrier that waits for it (2 per block, the first form: the last piece 2 blocks / 1
+    // block in front of it) -- same-box A/B (tools/experiments/x3_variants.sh): 2 / 3 / 4 / 5 per block = 841 / 835 / 832 / 838 us
+    // on [21120,1936,1936], 2 121 / 2 079 / 2 081 / 2 096 on [21120,5808,1936], 887 / 875 / 869 / 880 on [21120,2048,1936]
+    constexpr int PPB = X3_PPB;
     auto vmem_piece = [&](int n, int set_next, int step, unsigned char* stage) {
       if (n < X::CPW) { if constexpr (ABL != 3 && ABL != 5) glds_piece(n, step, stage); }
       else if (n < NVM) { if constexpr (ABL != 4 && ABL != 5) load_a1(set_next, step, (n - X::CPW) / 3, (n - X::CPW) % 3); }
@@ -245,7 +253,7 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
     read_b(smem_x3, 0, 0);
 
     // One K-step.  On entry fb[par] holds column block 0's fragments (read behind the previous barrier).  Block j runs its 12
-    // MFMAs with the 3 fragment reads of block j + 1 and two memory pieces of the NEXT K-step between them (a piece = one 1 KB
+    // MFMAs with the 3 fragment reads of block j + 1 and PPB memory pieces of the NEXT K-step between them (a piece = one 1 KB
     // LDS-DMA chunk of the weight tile or one A fragment: 14-15 per wave, spread over the first blocks -- issued in one burst
     // at the top of the step they held the wave for ~300 cycles before its first MFMA).  The LAST block is held over the
     // barrier: its MFMAs run after the next step's first fragment reads have been issued and cover the barrier wait and
@@ -260,19 +268,20 @@ gemm16x3_kernel(FmPlanes A, FmPlanes B, int M, int N, int K, int tiles_m, int ti
 #pragma unroll
       for (int j = 0; j + 1 < NB; ++j) {
         read_b(cur, j + 1, (par + j + 1) & 1);
-        vmem_piece(2 * j, set ^ 1, tn, nxt);
-        vmem_piece(2 * j + 1, set ^ 1, tn, nxt);
-        mma_block(set, j, (par + j) & 1);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int p = 0; p < PPB; ++p) vmem_piece(PPB * j + p, set ^ 1, tn, nxt);
+        mma_block(set, j, (par + j) & 1);
+        constexpr int GR = PPB > 3 ? PPB : 3;                       // groups of 2 MFMAs that carry a fragment read / a memory piece
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (r < 2 && 2 * j + r < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (r < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (r < PPB && PPB * j + r < NVM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        if constexpr (12 - 2 * GR > 0) __builtin_amdgcn_sched_group_barrier(0x008, 12 - 2 * GR, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      static_assert(2 * (NB - 1) >= NVM, "the next K-step's memory pieces must fit the blocks in front of the held-over one");
+      static_assert(PPB * (NB - 1) >= NVM && PPB <= 6, "the next K-step's memory pieces must fit the blocks in front of the held-over one");
       if constexpr (ABL != 2) __syncthreads();    // every wave has read `cur`; `nxt` and the next A fragments have landed
       read_b(nxt, 0, (par + NB) & 1);
       __builtin_amdgcn_sched_barrier(0);          // issue these reads BEFORE the held-over block, which then hides them
