@@ -492,44 +492,65 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
       HIPCK(launch_mask_conv1_pool(s, mask_base, mask_off, h->w0_perm, W(h, "conv.0.bias"), h->bn1_scale,
                                    h->bn1_shift, C2, (int)P));
     }
-    EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
-    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && h->w4_planes_fm &&
-                    (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
-    ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, P * 49, 1152), gemm_bytes(256, P * 49, 1152),
-                 x3 ? "gemm16x3c_kernel<Tile16<128,128>,AC_CONV2,EpiConvRows>"
-                    : conv_t16 ? "gemm16c_kernel<Tile16C<B_CONV2>,EpiConvT16>"
-                               : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, P * 49, 1152);
-    if (x3)
-      HIPCK(launch_mask_conv2_x3t16(s, h->w4_planes_fm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
-                                    h->L->slab.as<float>()));
-    else if (conv_t16)
-      HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P, h->L->slab.as<float>()));
-#ifdef STTRAN_GEMM_EXPERIMENT
-    else
-      HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->L->slab.as<float>()));
-#else
-    (void)e2;
-#endif
   }
   {
+    // conv3x3 -> ReLU -> BN into V, then V += union 1x1 conv (lib/sttran.py:342-345, :386-388).  Exact engine, launches of at
+    // least two rounds of tiles: ONE kernel for the whole rounds (the conv3x3's K range, its ReLU / BN on the accumulators,
+    // the union conv's K range on top, one store: pair_conv_fused_kernel), the two single-convolution launches for the
+    // leftover tiles only (tile_base).  Otherwise (small launches, the second engine) the two launches over everything.
     const Tensor& wu = h->w["union_func1.weight"];
-    const bool x3 = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes_fm && FD % 32 == 0 &&
-                    (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
-    ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * P * 256 * 49 * FD, 4.0 * P * (49.0 * FD + 2 * 12544) + 4.0 * 256 * FD,
-                 x3 ? "gemm16x3c_kernel<Tile16<128,128>,AC_UNION,EpiUnionRows>"
-                    : conv_t16 ? "gemm16c_kernel<Tile16C<B_UNION_FLAT>,EpiUnionT16>"
-                               : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, P * 49, FD);
-    if (x3)
-      HIPCK(launch_union_conv_x3t16(s, union_base, union_off, wu.planes_fm, W(h, "union_func1.bias"), V, (int)P, FD,
-                                    h->L->slab.as<float>()));
-    else if (conv_t16)
-      HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
-                                  h->L->slab.as<float>()));
-#ifdef STTRAN_GEMM_EXPERIMENT
-    else
-      HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
-                              h->L->slab.as<float>()));
+    const bool x3c = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && h->w4_planes_fm &&
+                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
+    const bool x3u = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes_fm && FD % 32 == 0 &&
+                     (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
+#ifdef STTRAN_NO_CONV_FUSION
+    const int ft = 0;
+#else
+    const int ft = (!x3c && !x3u && conv_t16 && FD % 32 == 0) ? pair_convs_fused_tiles((int)P) : 0;
 #endif
+    const int64_t ncols = (int64_t)P * 49, fcols = std::min<int64_t>(ncols, (int64_t)ft * 128), rcols = ncols - fcols;
+    if (ft) {
+      ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * 256 * fcols * (1152 + FD),
+                   4.0 * fcols * (FD + 128 + 256) + 4.0 * 256 * (FD + 1152), "pair_conv_fused_kernel<Tile16C>", 256, fcols, 1152 + FD);
+      HIPCK(launch_pair_convs_fused_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, union_base, union_off,
+                                        W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD, ft));
+    }
+    if (rcols > 0) {
+      EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, gemm_flops(256, rcols, 1152), gemm_bytes(256, rcols, 1152),
+                   x3c ? "gemm16x3c_kernel<Tile16<128,128>,AC_CONV2,EpiConvRows>"
+                       : conv_t16 ? "gemm16c_kernel<Tile16C<B_CONV2>,EpiConvT16>"
+                                  : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, rcols, 1152);
+      if (x3c)
+        HIPCK(launch_mask_conv2_x3t16(s, h->w4_planes_fm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
+                                      h->L->slab.as<float>()));
+      else if (conv_t16)
+        HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
+                                    h->L->slab.as<float>(), ft));
+#ifdef STTRAN_GEMM_EXPERIMENT
+      else
+        HIPCK(launch_mask_conv2(s, h->w4_perm, C2, e2, (int)P, h->L->slab.as<float>()));
+#else
+      (void)e2;
+#endif
+    }
+    if (rcols > 0) {
+      ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * 256 * rcols * FD, 4.0 * rcols * (FD + 2 * 256) + 4.0 * 256 * FD,
+                   x3u ? "gemm16x3c_kernel<Tile16<128,128>,AC_UNION,EpiUnionRows>"
+                       : conv_t16 ? "gemm16c_kernel<Tile16C<B_UNION_FLAT>,EpiUnionT16>"
+                                  : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, rcols, FD);
+      if (x3u)
+        HIPCK(launch_union_conv_x3t16(s, union_base, union_off, wu.planes_fm, W(h, "union_func1.bias"), V, (int)P, FD,
+                                      h->L->slab.as<float>()));
+      else if (conv_t16)
+        HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+                                    h->L->slab.as<float>(), ft));
+#ifdef STTRAN_GEMM_EXPERIMENT
+      else
+        HIPCK(launch_union_conv(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
+                                h->L->slab.as<float>()));
+#endif
+    }
   }
   if ((rc = run_linear(h, s, GemmOperand{V, 12544, nullptr}, W(h, "vr_fc.weight"), (int)P, 512, 12544,
                        epi_plain(X0 + 1024, LD, W(h, "vr_fc.bias"))))) return rc;

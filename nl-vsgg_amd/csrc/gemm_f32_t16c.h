@@ -46,15 +46,23 @@ struct Tile16C {
 // loop, 2 = no weight (A) loads, 3 = no loads at all, 4 = no loads and no ds_writes, 5 = no barrier, 6 = accumulators start
 // from zero (no V read at the tile start), 7 = no epilogue stores, 8 = the B loads are issued but nothing waits for them
 // (they land in registers the ds_writes do not read): separates their issue / bandwidth cost from their latency
-template <class T, class Epi, int ABL = 0>
-__global__ void __launch_bounds__(T::NT, 2)
-gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
-               int g_sk, int sk_base, int sk_rem, float* __restrict__ slab, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB, AV = T::AV, BV = T::BV, RPR = T::RPR;
+
+// One K range [ks0, ks0 + nsteps) of the tile at columns n0 .. n0 + 127 (all 256 channels: m0 = 0) accumulated into `acc`.
+// Shared by gemm16c_kernel (one convolution per launch) and pair_conv_fused_kernel (conv3x3, its ReLU / BN, then the union
+// conv's K range on the same accumulators).  On return every wave has passed the last barrier of the loop and reads the stage
+// buffers no more (what it still reads there is the unused look-ahead of a step that does not exist).
+template <class T, int ABL>
+__device__ __forceinline__ void conv_kloop(const GemmOperand& A, const GemmOperand& B, int N, int m0, int n0, int ks0, int nsteps,
+                                           float* smem, f32x4 (&acc)[2][T::NB]) {
+  constexpr int BM = T::BM, BN = T::BN, NB = T::NB, AV = T::AV, BV = T::BV, RPR = T::RPR;
   constexpr bool UFLAT = T::BKIND == B_UNION_FLAT;
   using Geo = ConvGeo<B_CONV2>;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the thread id through an opaque move: the index arithmetic below is then recomputed per call and dies with it (the fused
+  // kernel calls this twice per tile with different operand kinds: with everything derived from ONE threadIdx.x the compiler
+  // kept both phases' staging offsets and pointers alive across the whole tile loop and spilled)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int swz = (fr >> 1) & 7;
   const int frag0 = fr * kBK + ((fg ^ swz) << 2);          // kb = 0; kb = 1 is frag0 ^ 16
@@ -70,6 +78,234 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
     const int r = UFLAT ? ucol : srow + RPR * i, ch = UFLAT ? uch0 + i : schunk;
     st_b[i] = (BM + r) * kBK + ((ch ^ ((r >> 1) & 7)) << 2);
   }
+  // ---- sources of the staged pieces ---------------------------------------------------------------------------------
+  uint32_t oa[AV];                                           // weights: M = 256 rows exactly, K % 32 == 0 (launcher checks)
+#pragma unroll
+  for (int i = 0; i < AV; ++i) oa[i] = (uint32_t)((((int64_t)(m0 + srow + RPR * i)) * A.ld + schunk * 4 + ks0 * kBK) * 4);
+  const char* const abase = reinterpret_cast<const char*>(A.ptr);
+  const float* pb[BV];                                       // columns: a pointer per piece (the tensors exceed 4 GB)
+  int cy[BV], cx[BV];                                        // CONV2: input row / column of tap (0, 0), -100 = column past N
+  (void)cy; (void)cx;
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int n = n0 + (UFLAT ? ucol : srow + RPR * i);
+    const bool v = n < N;
+    const int nn = v ? n : 0, p = nn / kUHW, hw = nn - p * kUHW;
+    if constexpr (UFLAT) {
+      pb[i] = B.ptr + (B.rowoff ? B.rowoff[p] : (int64_t)p * B.ld) + hw + (int64_t)(uch0 + i) * 4 * kUHW;
+    } else {
+      const int oy = hw / Geo::HO, ox = hw - oy * Geo::HO;
+      cy[i] = v ? oy - Geo::PAD : -100; cx[i] = ox - Geo::PAD;
+      pb[i] = B.ptr + (int64_t)p * (Geo::CIN * Geo::HI * Geo::HI) + schunk * 4;
+    }
+  }
+  f32x4 ra[2][AV], rb[2][BV];
+  f32x4 rbx[2][BV];                                          // ABL 8 only
+  (void)rbx;
+  bool zb[2][BV];                                            // CONV2: the piece is a zero piece (tap outside the image)
+  (void)zb;
+  auto kstep_of = [&](int step) { return ks0 + (step < nsteps ? step : 0); };   // steps past the end re-read step 0 (unused)
+  // load slot n of a K-step: AV weight pieces, then the column pieces (a UNION piece is four dword loads, each its own slot)
+  // LOAD order (round 4, union conv only): the column operand first, the weights last -- union_feat comes from HBM, the
+  // weights are 2 MB that every tile re-reads from L2; the column pieces get a quarter of a K-step more time in flight:
+  // 4 246 vs 4 270 us in situ (conv3x3, whose gathered operand is cache-resident, lost 0.6 % with it and keeps the old
+  // order).  Slot m of the K-step loads piece n = (m + AV) mod NLS.
+  constexpr int NLS = AV + (UFLAT ? 4 * BV : BV);
+  auto load_slot = [&](int set, int m, int step) {
+    const int ks = kstep_of(step);
+    const int n = !UFLAT ? m : (m < NLS - AV ? m + AV : m - (NLS - AV));
+    if (n < AV) {
+      ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)((ks - ks0) * kBK * 4)));
+    } else if constexpr (UFLAT) {
+      const int i = (n - AV) >> 2, e = (n - AV) & 3;
+      if constexpr (ABL == 8) rbx[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
+      else rb[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
+    } else {
+      const int i = n - AV;
+      const int k0 = ks * kBK, tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH, ci0 = k0 - tap * Geo::CIN;
+      const int iy = cy[i] + ky, ix = cx[i] + kx;
+      const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
+      if constexpr (ABL == 8) rbx[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
+      else rb[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
+      zb[set][i] = !ok;
+    }
+  };
+  constexpr int NP = AV + BV;
+  auto store_piece = [&](int set, int n, float* stage) {
+    if (n < AV) *reinterpret_cast<f32x4*>(stage + st_a + n * RPR * kBK) = ra[set][n];
+    else {
+      const int i = n - AV;
+      if constexpr (UFLAT) *reinterpret_cast<f32x4*>(stage + st_b[i]) = rb[set][i];
+      else *reinterpret_cast<f32x4*>(stage + st_b[i]) = zb[set][i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[set][i];
+    }
+  };
+
+  constexpr int NBLK = 2 * NB;
+  static_assert(NLS <= NBLK - 1 && NP <= NBLK - 1, "staging slots must fit the blocks of a K-step");
+#pragma unroll
+  for (int n = 0; n < NLS; ++n) load_slot(0, n, 0);
+#pragma unroll
+  for (int n = 0; n < NLS; ++n) load_slot(1, n, 1);
+#pragma unroll
+  for (int n = 0; n < NP; ++n) store_piece(0, n, smem);
+  __syncthreads();
+
+  f32x4 fa[2][2], fb[2];
+  auto read_a = [&](const float* stage, int kb) {
+    const int fo = kb ? (frag0 ^ 16) : frag0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[kb][i] = *reinterpret_cast<const f32x4*>(stage + a_base + i * 16 * kBK + fo);
+  };
+  auto read_b = [&](const float* stage, int sblk) {
+    const int kb = sblk / NB, j = sblk - kb * NB;
+    fb[sblk & 1] = *reinterpret_cast<const f32x4*>(stage + (BM + j * 16) * kBK + (kb ? (frag0 ^ 16) : frag0));
+  };
+  auto mma_block = [&](int sblk) {
+    const int kb = sblk / NB, j = sblk - kb * NB;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kb][i][e], fb[sblk & 1][e], acc[i][j], 0, 0, 0);
+  };
+  read_a(smem, 0);
+  read_b(smem, 0);
+  auto k_step = [&](int t, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    const float* cur = smem + set * T::STAGE;
+    float* nxt = smem + (set ^ 1) * T::STAGE;
+#pragma unroll
+    for (int sb = 0; sb < NBLK; ++sb) {
+      if (sb + 1 < NBLK) read_b(cur, sb + 1);
+      if (sb == NB - 3) read_a(cur, 1);
+      constexpr bool kLoadB = ABL != 1 && ABL != 3 && ABL != 4, kLoadA = ABL != 2 && ABL != 3 && ABL != 4, kStore = ABL != 4;
+      if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) load_slot(set, sb, t + 2);
+      if (sb >= NBLK - NP && kStore) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
+      if (sb + 1 < NBLK) {
+        mma_block(sb);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (sb >= NBLK - NP && kStore) {
+          if constexpr (!UFLAT) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ABL != 5) __syncthreads();
+    read_a(nxt, 0);
+    read_b(nxt, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_block(NBLK - 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+      k_step(t, std::integral_constant<int, 0>{});
+      k_step(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
+  }
+
+  if constexpr (ABL == 8) {
+#pragma unroll
+    for (int i = 0; i < BV; ++i) asm volatile("" ::"v"(rbx[0][i]), "v"(rbx[1][i]));
+  }
+}
+
+// The finished tile (all of its K range in `acc`) through the epilogue: value() per element, then out through the wave's LDS block
+template <class T, class Epi, int ABL>
+__device__ __forceinline__ void conv_store_tile(const Epi& epi, int N, int m0, int n0, float* smem, f32x4 (&acc)[2][T::NB]) {
+  constexpr int BN = T::BN, NB = T::NB;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));                      // (see conv_kloop)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ch0 = m0 + wave * 32 + 4 * fg;
+  // Whole tile.  Round 3-4 stored straight from the accumulators: a lane holds four CHANNELS of one column, so a store
+  // instruction wrote 4 x 64 contiguous bytes (16 hw of 4 channels) and a tile took 64 dword stores per lane (2.8-4.3 % of
+  // the kernel by ablation).  Now the finished values cross the wave's own LDS block (16 channels x 128 columns per pass,
+  // rows 132 floats apart) and leave as 16-byte pieces of four consecutive hw: a [49]-float row of V starts at any
+  // multiple of 4 bytes, which global memory takes for a dwordx4 access.  A piece that would run over a pair's last hw
+  // (the tile's columns run straight over the pair borders: at most three such pieces in 128 columns) or over column N
+  // is left out of the 16-byte pass; those few pieces x 16 channels are spread over the lanes of a second, dword pass.
+  constexpr int EPS = BN + 4;                        // floats per LDS row: 528 bytes = 33 sixteen-byte slots
+  static_assert(8 * 16 * EPS * 4 <= T::LDS_BYTES, "eight wave blocks fit the stage buffers");
+  typename Epi::Consts cst[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cst[i][v] = epi.consts(ch0 + 16 * i + v);
+  // this lane's piece of every row it handles: columns n0 + 4 q .. + 3
+  const int q = lane & 31, c0 = n0 + 4 * q;
+  const int pq = c0 / kUHW, hwq = c0 - pq * kUHW;
+  const bool whole = hwq + 3 < kUHW && c0 + 3 < N;  // inside one pair, inside the operand
+  float* const vq = whole ? epi.addr(m0 + wave * 32 + (lane >> 5), c0) : nullptr;
+  // the pieces left to the dword pass: the one before every pair border inside the tile (unless the border falls on a
+  // piece border) and the one that holds column N
+  int odd[4], nodd = 0;
+  {
+    const int b0 = (n0 + kUHW - 1) / kUHW * kUHW;   // first pair border >= n0
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int b = b0 + k * kUHW, r = b - n0;
+      if (r < BN && b < N && (r & 3)) odd[nodd++] = r >> 2;
+    }
+    if (N - n0 < BN && N > n0 && ((N - n0) & 3)) odd[nodd++] = (N - n0) >> 2;
+  }
+  __syncthreads();                                   // every wave is done with the stage buffers
+  float* const ep = smem + wave * (16 * EPS);
+  const bool keep = ABL != 7 || acc[0][0][0] == 12345.678f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ep[(4 * fg + v) * EPS + 16 * j + fr] = epi.value(acc[i][j][v], cst[i][v]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the block is private to this wave: program order is enough
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (whole && keep) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {                  // rows (lane >> 5) + 2 u of the pass, 16 bytes each
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ep + ((lane >> 5) + 2 * u) * EPS + 4 * q);
+        reinterpret_cast<V4a4*>(vq + (int64_t)(16 * i + 2 * u) * kUHW)->v = val;
+      }
+    }
+    if (nodd && keep) {                              // (item = odd piece x row) per lane, four dword stores each
+      for (int it = lane; it < nodd * 16; it += 64) {
+        const int k = it >> 4, r = it & 15, qq = k == 0 ? odd[0] : k == 1 ? odd[1] : k == 2 ? odd[2] : odd[3];
+        const f32x4 val = *reinterpret_cast<const f32x4*>(ep + r * EPS + 4 * qq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = n0 + 4 * qq + e;
+          if (col < N) *epi.addr(m0 + wave * 32 + 16 * i + r, col) = val[e];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next pass's writes stay behind these reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();                                   // the next tile's first K-step is staged over these blocks
+}
+
+template <class T, class Epi, int ABL = 0>
+__global__ void __launch_bounds__(T::NT, 2)
+gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, int tiles, int ksteps, int dp_per_wg,
+               int g_sk, int sk_base, int sk_rem, int tile_base, float* __restrict__ slab, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT, NB = T::NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
 
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);
@@ -90,72 +326,11 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
       ks0 = it - t * ksteps;
       ks1 = min(ksteps, ks0 + (rg.end - it));
     }
+    tile += tile_base;                                         // a launch over the tiles behind pair_conv_fused_kernel's
     const int nsteps = ks1 - ks0;
     int tile_m, tile_n;
     tile_origin<T::GROUP_N>(tile, tiles_m, tiles / tiles_m, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- sources of the staged pieces ---------------------------------------------------------------------------------
-    uint32_t oa[AV];                                           // weights: M = 256 rows exactly, K % 32 == 0 (launcher checks)
-#pragma unroll
-    for (int i = 0; i < AV; ++i) oa[i] = (uint32_t)((((int64_t)(m0 + srow + RPR * i)) * A.ld + schunk * 4 + ks0 * kBK) * 4);
-    const char* const abase = reinterpret_cast<const char*>(A.ptr);
-    const float* pb[BV];                                       // columns: a pointer per piece (the tensors exceed 4 GB)
-    int cy[BV], cx[BV];                                        // CONV2: input row / column of tap (0, 0), -100 = column past N
-    (void)cy; (void)cx;
-#pragma unroll
-    for (int i = 0; i < BV; ++i) {
-      const int n = n0 + (UFLAT ? ucol : srow + RPR * i);
-      const bool v = n < N;
-      const int nn = v ? n : 0, p = nn / kUHW, hw = nn - p * kUHW;
-      if constexpr (UFLAT) {
-        pb[i] = B.ptr + (B.rowoff ? B.rowoff[p] : (int64_t)p * B.ld) + hw + (int64_t)(uch0 + i) * 4 * kUHW;
-      } else {
-        const int oy = hw / Geo::HO, ox = hw - oy * Geo::HO;
-        cy[i] = v ? oy - Geo::PAD : -100; cx[i] = ox - Geo::PAD;
-        pb[i] = B.ptr + (int64_t)p * (Geo::CIN * Geo::HI * Geo::HI) + schunk * 4;
-      }
-    }
-    f32x4 ra[2][AV], rb[2][BV];
-    f32x4 rbx[2][BV];                                          // ABL 8 only
-    (void)rbx;
-    bool zb[2][BV];                                            // CONV2: the piece is a zero piece (tap outside the image)
-    (void)zb;
-    auto kstep_of = [&](int step) { return ks0 + (step < nsteps ? step : 0); };   // steps past the end re-read step 0 (unused)
-    // load slot n of a K-step: AV weight pieces, then the column pieces (a UNION piece is four dword loads, each its own slot)
-    // LOAD order (round 4, union conv only): the column operand first, the weights last -- union_feat comes from HBM, the
-    // weights are 2 MB that every tile re-reads from L2; the column pieces get a quarter of a K-step more time in flight:
-    // 4 246 vs 4 270 us in situ (conv3x3, whose gathered operand is cache-resident, lost 0.6 % with it and keeps the old
-    // order).  Slot m of the K-step loads piece n = (m + AV) mod NLS.
-    constexpr int NLS = AV + (UFLAT ? 4 * BV : BV);
-    auto load_slot = [&](int set, int m, int step) {
-      const int ks = kstep_of(step);
-      const int n = !UFLAT ? m : (m < NLS - AV ? m + AV : m - (NLS - AV));
-      if (n < AV) {
-        ra[set][n] = *reinterpret_cast<const f32x4*>(abase + (oa[n] + (uint32_t)((ks - ks0) * kBK * 4)));
-      } else if constexpr (UFLAT) {
-        const int i = (n - AV) >> 2, e = (n - AV) & 3;
-        if constexpr (ABL == 8) rbx[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
-        else rb[set][i][e] = pb[i][((int64_t)ks * kBK + e) * kUHW];
-      } else {
-        const int i = n - AV;
-        const int k0 = ks * kBK, tap = k0 / Geo::CIN, ky = tap / Geo::KH, kx = tap - ky * Geo::KH, ci0 = k0 - tap * Geo::CIN;
-        const int iy = cy[i] + ky, ix = cx[i] + kx;
-        const bool ok = (unsigned)iy < (unsigned)Geo::HI && (unsigned)ix < (unsigned)Geo::HI;
-        if constexpr (ABL == 8) rbx[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
-        else rb[set][i] = *reinterpret_cast<const f32x4*>(pb[i] + (ok ? (iy * Geo::HI + ix) * Geo::CIN + ci0 : 0));
-        zb[set][i] = !ok;
-      }
-    };
-    constexpr int NP = AV + BV;
-    auto store_piece = [&](int set, int n, float* stage) {
-      if (n < AV) *reinterpret_cast<f32x4*>(stage + st_a + n * RPR * kBK) = ra[set][n];
-      else {
-        const int i = n - AV;
-        if constexpr (UFLAT) *reinterpret_cast<f32x4*>(stage + st_b[i]) = rb[set][i];
-        else *reinterpret_cast<f32x4*>(stage + st_b[i]) = zb[set][i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rb[set][i];
-      }
-    };
 
     // accumulators: lane (fr, fg) holds, for row block i and column block j, channels 32 w + 16 i + 4 fg + {0..3} of
     // column n0 + 16 j + fr
@@ -188,152 +363,9 @@ gemm16c_kernel(GemmOperand A, GemmOperand B, int M, int N, int K, int tiles_m, i
         for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    constexpr int NBLK = 2 * NB;
-    static_assert(NLS <= NBLK - 1 && NP <= NBLK - 1, "staging slots must fit the blocks of a K-step");
-#pragma unroll
-    for (int n = 0; n < NLS; ++n) load_slot(0, n, 0);
-#pragma unroll
-    for (int n = 0; n < NLS; ++n) load_slot(1, n, 1);
-#pragma unroll
-    for (int n = 0; n < NP; ++n) store_piece(0, n, smem);
-    __syncthreads();
-
-    f32x4 fa[2][2], fb[2];
-    auto read_a = [&](const float* stage, int kb) {
-      const int fo = kb ? (frag0 ^ 16) : frag0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[kb][i] = *reinterpret_cast<const f32x4*>(stage + a_base + i * 16 * kBK + fo);
-    };
-    auto read_b = [&](const float* stage, int sblk) {
-      const int kb = sblk / NB, j = sblk - kb * NB;
-      fb[sblk & 1] = *reinterpret_cast<const f32x4*>(stage + (BM + j * 16) * kBK + (kb ? (frag0 ^ 16) : frag0));
-    };
-    auto mma_block = [&](int sblk) {
-      const int kb = sblk / NB, j = sblk - kb * NB;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kb][i][e], fb[sblk & 1][e], acc[i][j], 0, 0, 0);
-    };
-    read_a(smem, 0);
-    read_b(smem, 0);
-    auto k_step = [&](int t, auto set_c) {
-      constexpr int set = decltype(set_c)::value;
-      const float* cur = smem + set * T::STAGE;
-      float* nxt = smem + (set ^ 1) * T::STAGE;
-#pragma unroll
-      for (int sb = 0; sb < NBLK; ++sb) {
-        if (sb + 1 < NBLK) read_b(cur, sb + 1);
-        if (sb == NB - 3) read_a(cur, 1);
-        constexpr bool kLoadB = ABL != 1 && ABL != 3 && ABL != 4, kLoadA = ABL != 2 && ABL != 3 && ABL != 4, kStore = ABL != 4;
-        if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) load_slot(set, sb, t + 2);
-        if (sb >= NBLK - NP && kStore) store_piece(set ^ 1, sb - (NBLK - NP), nxt);
-        if (sb + 1 < NBLK) {
-          mma_block(sb);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (sb < NLS && ((UFLAT ? sb >= NLS - AV : sb < AV) ? kLoadA : kLoadB)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          if (sb >= NBLK - NP && kStore) {
-            if constexpr (!UFLAT) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (sb == NB - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (ABL != 5) __syncthreads();
-      read_a(nxt, 0);
-      read_b(nxt, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_block(NBLK - 1);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    {
-      int t = 0;
-      for (; t + 1 < nsteps; t += 2) {
-        k_step(t, std::integral_constant<int, 0>{});
-        k_step(t + 1, std::integral_constant<int, 1>{});
-      }
-      if (t < nsteps) k_step(t, std::integral_constant<int, 0>{});
-    }
-
-    if constexpr (ABL == 8) {
-#pragma unroll
-      for (int i = 0; i < BV; ++i) asm volatile("" ::"v"(rbx[0][i]), "v"(rbx[1][i]));
-    }
+    conv_kloop<T, ABL>(A, B, N, m0, n0, ks0, nsteps, smem, acc);
     if (nsteps == ksteps) {
-      // Whole tile.  Round 3-4 stored straight from the accumulators: a lane holds four CHANNELS of one column, so a store
-      // instruction wrote 4 x 64 contiguous bytes (16 hw of 4 channels) and a tile took 64 dword stores per lane (2.8-4.3 % of
-      // the kernel by ablation).  Now the finished values cross the wave's own LDS block (16 channels x 128 columns per pass,
-      // rows 132 floats apart) and leave as 16-byte pieces of four consecutive hw: a [49]-float row of V starts at any
-      // multiple of 4 bytes, which global memory takes for a dwordx4 access.  A piece that would run over a pair's last hw
-      // (the tile's columns run straight over the pair borders: at most three such pieces in 128 columns) or over column N
-      // is left out of the 16-byte pass; those few pieces x 16 channels are spread over the lanes of a second, dword pass.
-      constexpr int EPS = BN + 4;                        // floats per LDS row: 528 bytes = 33 sixteen-byte slots
-      static_assert(8 * 16 * EPS * 4 <= T::LDS_BYTES, "eight wave blocks fit the stage buffers");
-      typename Epi::Consts cst[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) cst[i][v] = epi.consts(ch0 + 16 * i + v);
-      // this lane's piece of every row it handles: columns n0 + 4 q .. + 3
-      const int q = lane & 31, c0 = n0 + 4 * q;
-      const int pq = c0 / kUHW, hwq = c0 - pq * kUHW;
-      const bool whole = hwq + 3 < kUHW && c0 + 3 < N;  // inside one pair, inside the operand
-      float* const vq = whole ? epi.addr(m0 + wave * 32 + (lane >> 5), c0) : nullptr;
-      // the pieces left to the dword pass: the one before every pair border inside the tile (unless the border falls on a
-      // piece border) and the one that holds column N
-      int odd[4], nodd = 0;
-      {
-        const int b0 = (n0 + kUHW - 1) / kUHW * kUHW;   // first pair border >= n0
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int b = b0 + k * kUHW, r = b - n0;
-          if (r < BN && b < N && (r & 3)) odd[nodd++] = r >> 2;
-        }
-        if (N - n0 < BN && N > n0 && ((N - n0) & 3)) odd[nodd++] = (N - n0) >> 2;
-      }
-      __syncthreads();                                   // every wave is done with the stage buffers
-      float* const ep = smem + wave * (16 * EPS);
-      const bool keep = ABL != 7 || acc[0][0][0] == 12345.678f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) ep[(4 * fg + v) * EPS + 16 * j + fr] = epi.value(acc[i][j][v], cst[i][v]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the block is private to this wave: program order is enough
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (whole && keep) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {                  // rows (lane >> 5) + 2 u of the pass, 16 bytes each
-            const f32x4 val = *reinterpret_cast<const f32x4*>(ep + ((lane >> 5) + 2 * u) * EPS + 4 * q);
-            reinterpret_cast<V4a4*>(vq + (int64_t)(16 * i + 2 * u) * kUHW)->v = val;
-          }
-        }
-        if (nodd && keep) {                              // (item = odd piece x row) per lane, four dword stores each
-          for (int it = lane; it < nodd * 16; it += 64) {
-            const int k = it >> 4, r = it & 15, qq = k == 0 ? odd[0] : k == 1 ? odd[1] : k == 2 ? odd[2] : odd[3];
-            const f32x4 val = *reinterpret_cast<const f32x4*>(ep + r * EPS + 4 * qq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int col = n0 + 4 * qq + e;
-              if (col < N) *epi.addr(m0 + wave * 32 + 16 * i + r, col) = val[e];
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next pass's writes stay behind these reads
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-      __syncthreads();                                   // the next tile's first K-step is staged over these blocks
+      conv_store_tile<T, Epi, ABL>(epi, N, m0, n0, smem, acc);
     } else {
       f32x4* sp = reinterpret_cast<f32x4*>(slab + ((int64_t)blk * 2 + (it == rg.begin ? 0 : 1)) * (BM * BN)) + tid;
 #pragma unroll
@@ -411,5 +443,49 @@ struct EpiConvT16 {
   }
   __device__ __forceinline__ void store(int row, int col, float v, const Consts& c) const { *addr(row, col) = value(v, c); }
 };
+
+// ---- both convolutions of a pair block in ONE pass over the tile (round 6) ------------------------------------------------------
+// V[p][ch][hw] = BN(ReLU(conv3x3(C2) + b4)) + union_func1(U) + b1   (lib/sttran.py:342-345 + :386-387, summed at :388).
+// As two launches the conv3x3 stores its 256 x 128 tile (64 store instructions per lane) and the union conv reads it back as
+// its accumulators' start values (64 loads per lane): 2 x 565 MB at 64 clips of 16x12, one pipeline fill and drain per tile
+// and launch, one fix-up launch.  Here a workgroup runs the conv3x3's 36 K-steps, applies bias / ReLU / BN to the
+// accumulators in registers, runs the union conv's K-steps ON THEM and stores once -- the same arithmetic in the same order
+// (bit-identical to the two launches on tiles neither of them splits).  The ReLU between the two K ranges makes a tile
+// indivisible for stream-K, so this kernel takes only the launch's WHOLE rounds of tiles (dp_per_wg per workgroup); the
+// leftover tiles go through the two single-convolution launches with `tile_base` (their stream-K balances the tail).
+template <int ABL = 0>
+__global__ void __launch_bounds__(Tile16C<B_CONV2>::NT, 2)
+pair_conv_fused_kernel(GemmOperand A2, GemmOperand B2, GemmOperand A1, GemmOperand B1, int N, int K1, int dp_per_wg, EpiConvT16 e2,
+                       EpiUnionT16 e1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using T2 = Tile16C<B_CONV2>;
+  using T1 = Tile16C<B_UNION_FLAT>;
+  constexpr int NB = T2::NB;
+  static_assert(T1::LDS_BYTES == T2::LDS_BYTES && T1::NT == T2::NT && T1::BN == T2::BN, "one tile geometry");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fg = lane >> 4;
+  const int G = gridDim.x;
+  const int blk = xcd_remap(blockIdx.x, G);
+  const int ch0 = wave * 32 + 4 * fg;
+  for (int d = 0; d < dp_per_wg; ++d) {
+    const int n0 = (d * G + blk) * T2::BN;
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv_kloop<T2, ABL>(A2, B2, N, 0, n0, 0, ConvGeo<B_CONV2>::KREAL / kBK, smem, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const EpiConvT16::Consts c = e2.consts(ch0 + 16 * i + v);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j][v] = e2.value(acc[i][j][v], c);
+      }
+    conv_kloop<T1, ABL>(A1, B1, N, 0, n0, 0, K1 / kBK, smem, acc);
+    conv_store_tile<T1, EpiUnionT16, ABL>(e1, N, 0, n0, smem, acc);
+  }
+}
 
 }  // namespace sttran

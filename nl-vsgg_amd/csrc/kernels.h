@@ -66,10 +66,17 @@ hipError_t launch_mask_conv2(hipStream_t s, const float* w4, const float* c2, co
                              float* slab);
 
 // the same two convolutions on the 16x16x4 kernel structure (gemm_f32_t16c.h): the product path since round 3
+// (tile_base: the launch covers the 128-column tiles from there on -- the ones behind the fused launch's)
 hipError_t launch_union_conv_t16(hipStream_t s, const float* U, const int64_t* u_off, const float* W, const float* bias, float* V,
-                                 int P, int K, float* slab);
+                                 int P, int K, float* slab, int tile_base = 0);
 hipError_t launch_mask_conv2_t16(hipStream_t s, const float* w4, const float* c2, const float* bias, const float* scale,
-                                 const float* shift, float* V, int P, float* slab);
+                                 const float* shift, float* V, int P, float* slab, int tile_base = 0);
+// both of them in one pass over a tile (pair_conv_fused_kernel, gemm_f32_t16c.h): the first pair_convs_fused_tiles(P) column
+// tiles of a launch (0 = the launch is too small for it); the rest goes through the two launches above with tile_base
+int pair_convs_fused_tiles(int P);
+hipError_t launch_pair_convs_fused_t16(hipStream_t s, const float* w4, const float* c2, const float* bias4, const float* scale,
+                                       const float* shift, const float* U, const int64_t* u_off, const float* W, const float* bias1,
+                                       float* V, int P, int K, int ntiles);
 
 hipError_t launch_mfma_peak(hipStream_t s, float* out, int iters, int blocks);
 

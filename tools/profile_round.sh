@@ -41,13 +41,13 @@ for c in FETCH_SIZE WRITE_SIZE; do pmc dsg $c --model dsgdetr --steps 3 --warmup
 python3 tools/pmc_traffic.py "$O/${P}_pmc_dsg_FETCH_SIZE" "$O/${P}_pmc_dsg_WRITE_SIZE" "$C" 64 > "$O/${P}_pmc_traffic_dsgdetr_16x12.json"
 # 3. MFMA-pipe occupancy of the dominant kernels (one counter per pass)
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU; do pmc busy $c --steps 3 --warmup 1; done
-for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "EpiUnionT16" "EpiConvT16"; do
+for k in "gemm16_kernel<sttran::Tile16<128, 176>" "gemm16_kernel<sttran::Tile16<128, 128>" "pair_conv_fused_kernel"; do
   tag=$(echo "$k" | tr -c 'A-Za-z0-9' '_' | cut -c1-40)
   python3 tools/pmc_mfma_busy.py "$O/${P}_pmc_busy_" "$k" "$C" > "$O/${P}_pmc_mfma_busy_$tag.json"
 done
 # ... and of every kernel class of the step side by side, the non-GEMM kernels included (round 5)
-python3 tools/pmc_kernels.py "$O/${P}_pmc_busy_" "$C" mask_conv1_pool_kernel attention_short_kernel layernorm_kernel EpiUnionT16 EpiConvT16 \
-  "Tile16<128, 176>" "Tile16<128, 128>" > "$O/${P}_pmc_kernels.json"
+python3 tools/pmc_kernels.py "$O/${P}_pmc_busy_" "$C" mask_conv1_pool_kernel attention_short_kernel layernorm_kernel pair_conv_fused_kernel \
+  "gemm16c_kernel<sttran::Tile16C<4>" "gemm16c_kernel<sttran::Tile16C<2>" "Tile16<128, 176>" "Tile16<128, 128>" > "$O/${P}_pmc_kernels.json"
 # ... and of the second engine's kernels (round 6: gemm16x3_kernel / gemm16x3c_kernel / split_fm_kernel)
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU; do pmc busyx3 $c --gemm-engine bf16x3 --steps 3 --warmup 1; done
 python3 tools/pmc_kernels.py "$O/${P}_pmc_busyx3_" "$C" "gemm16x3_kernel<sttran::Tile16<128, 176>" "gemm16x3_kernel<sttran::Tile16<128, 128>" \
