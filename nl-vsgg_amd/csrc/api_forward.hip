@@ -504,16 +504,23 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
     const bool x3u = h->gemm_engine != STTRAN_GEMM_FP32_MFMA && h->planes_ready && wu.planes_fm && FD % 32 == 0 &&
                      (P * 49 >= 512 || h->gemm_engine == STTRAN_GEMM_BF16X3_ALL);
 #ifdef STTRAN_NO_CONV_FUSION
-    const int ft = 0;
+    const int ft = 0, ft3 = 0;
 #else
-    const int ft = (!x3c && !x3u && conv_t16 && FD % 32 == 0) ? pair_convs_fused_tiles((int)P) : 0;
+    const int ft = (!x3c && !x3u && conv_t16 && FD % 32 == 0) ? pair_convs_fused_tiles((int)P) : 0;       // tiles of 128 columns
+    const int ft3 = (x3c && x3u) ? pair_convs_fused_tiles_x3((int)P) : 0;                                  // tiles of 128 rows x 128 channels
 #endif
-    const int64_t ncols = (int64_t)P * 49, fcols = std::min<int64_t>(ncols, (int64_t)ft * 128), rcols = ncols - fcols;
-    if (ft) {
+    const int64_t ncols = (int64_t)P * 49, fcols = std::min<int64_t>(ncols, ft ? (int64_t)ft * 128 : (int64_t)(ft3 / 2) * 128),
+                  rcols = ncols - fcols;
+    if ((ft | ft3) != 0) {
       ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * 256 * fcols * (1152 + FD),
-                   4.0 * fcols * (FD + 128 + 256) + 4.0 * 256 * (FD + 1152), "pair_conv_fused_kernel<Tile16C>", 256, fcols, 1152 + FD);
-      HIPCK(launch_pair_convs_fused_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, union_base, union_off,
-                                        W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD, ft));
+                   4.0 * fcols * (FD + 128 + 256) + 4.0 * 256 * (FD + 1152),
+                   ft ? "pair_conv_fused_kernel<Tile16C>" : "pair_conv_fused_x3_kernel<Tile16<128,128>>", 256, fcols, 1152 + FD);
+      if (ft)
+        HIPCK(launch_pair_convs_fused_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, union_base, union_off,
+                                          W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD, ft));
+      else
+        HIPCK(launch_pair_convs_fused_x3t16(s, h->w4_planes_fm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, union_base,
+                                            union_off, wu.planes_fm, W(h, "union_func1.bias"), V, (int)P, FD, ft3));
     }
     if (rcols > 0) {
       EpiConvRelBn e2{V, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, 256, 49};
@@ -523,7 +530,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                                   : "gemm_sk_kernel<GemmTile<256,128,4,2,B_CONV2>,EpiConvRelBn>", 256, rcols, 1152);
       if (x3c)
         HIPCK(launch_mask_conv2_x3t16(s, h->w4_planes_fm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
-                                      h->L->slab.as<float>()));
+                                      h->L->slab.as<float>(), ft3));
       else if (conv_t16)
         HIPCK(launch_mask_conv2_t16(s, h->w4_perm, C2, W(h, "conv.4.bias"), h->bn2_scale, h->bn2_shift, V, (int)P,
                                     h->L->slab.as<float>(), ft));
@@ -541,7 +548,7 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
                                   : "gemm_sk_kernel<GemmTile<256,128,4,2,B_UNION_FLAT>,EpiUnionFlat>", 256, rcols, FD);
       if (x3u)
         HIPCK(launch_union_conv_x3t16(s, union_base, union_off, wu.planes_fm, W(h, "union_func1.bias"), V, (int)P, FD,
-                                      h->L->slab.as<float>()));
+                                      h->L->slab.as<float>(), ft3));
       else if (conv_t16)
         HIPCK(launch_union_conv_t16(s, union_base, union_off, W(h, "union_func1.weight"), W(h, "union_func1.bias"), V, (int)P, FD,
                                     h->L->slab.as<float>(), ft));

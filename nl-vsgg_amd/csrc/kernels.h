@@ -114,9 +114,15 @@ hipError_t gemm_res_planes_x3t16(hipStream_t s, const void* a_planes, const void
 // the two convolutions on the same engine (gemm_bf16x3_t16c.h): planes_fm = fragment-major planes (split_fm, weight = 1) of the
 // [256, K] / [256, 1152] weight
 hipError_t launch_union_conv_x3t16(hipStream_t s, const float* U, const int64_t* u_off, const void* planes_fm, const float* bias,
-                                   float* V, int P, int K, float* slab);
+                                   float* V, int P, int K, float* slab, int tile_base = 0);
 hipError_t launch_mask_conv2_x3t16(hipStream_t s, const void* planes_fm, const float* c2, const float* bias, const float* scale,
-                                   const float* shift, float* V, int P, float* slab);
+                                   const float* shift, float* V, int P, float* slab, int tile_base = 0);
+// ... and both in one pass over a tile (pair_conv_fused_x3_kernel), as launch_pair_convs_fused_t16 above (tiles of 128 rows x 128
+// channels here: tile_base counts those)
+int pair_convs_fused_tiles_x3(int P);
+hipError_t launch_pair_convs_fused_x3t16(hipStream_t s, const void* w4_planes_fm, const float* c2, const float* bias4, const float* scale,
+                                         const float* shift, const float* U, const int64_t* u_off, const void* wu_planes_fm,
+                                         const float* bias1, float* V, int P, int K, int ntiles);
 
 // ---- fusion front-end (lib/sttran.py:381-399) ----------------------------------------------
 // Where the inputs of one call live: n chunks, chunk c = the tensors of one clip as the caller passed them (SttranInputs'

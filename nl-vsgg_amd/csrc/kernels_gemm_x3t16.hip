@@ -120,7 +120,8 @@ hipError_t gemm_res_planes_x3t16(hipStream_t s, const void* a_planes, const void
 
 // ---- the two convolutions (gemm_bf16x3_t16c.h): activations loaded as fp32 and split in registers, weights fragment-major ----
 template <int AKIND, class Epi>
-static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPlanes& B, int M, int N, int K, const Epi& e, float* slab) {
+static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPlanes& B, int M, int N, int K, const Epi& e, float* slab,
+                                int tile_base) {
   using T = Tile16<128, 128>;
   static DeviceMarks marks;
   auto kern = gemm16x3c_kernel<T, AKIND, Epi>;
@@ -128,7 +129,9 @@ static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPla
     hipError_t er = marks.raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES);
     if (er != hipSuccess) return er;
   }
-  const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles = tm * tn;
+  const int tm = (M + T::BM - 1) / T::BM, tn = N / T::BN, tiles_all = tm * tn;
+  if (tile_base < 0 || tile_base >= tiles_all || (tile_base & 1)) return hipErrorInvalidValue;
+  const int tiles = tiles_all - tile_base;         // tile_base > 0: the tiles behind the fused launch's
   const int ksteps = K / kBK;
   const SkPlan sp = sk_plan(TILE_T128x128, tiles, ksteps);
   const int64_t total = (int64_t)sp.tiles_sk * ksteps;
@@ -138,32 +141,63 @@ static hipError_t launch_x3t16c(hipStream_t s, const GemmOperand& A, const FmPla
   for (int b = 1; b < sp.g_sk && !split; ++b) split = (sk_range(b, base, rem).begin % ksteps) != 0;
   if (split && !slab) return hipErrorInvalidValue;
   const int half = 2;                              // both N-tiles of an M-panel side by side: the activation rows are read once
-  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles, ksteps, sp.dp_per_wg, sp.g_sk,
-                     base, rem, half, slab, e);
+  hipLaunchKernelGGL(kern, dim3(sp.G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A, B, M, N, K, tm, tiles_all, ksteps, sp.dp_per_wg, sp.g_sk,
+                     base, rem, half, tile_base, slab, e);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess || !split) return err;
   hipLaunchKernelGGL((gemm16_fixup_kernel<T, Epi>), dim3(sp.tiles_sk, 2 * T::NB), dim3(T::NT), 0, s, M, N, tm, tn, ksteps, sp.g_sk,
-                     base, rem, tiles - sp.tiles_sk, half, slab, e);
+                     base, rem, tile_base + tiles - sp.tiles_sk, half, slab, e);
   return hipGetLastError();
 }
 
 // union_func1: V[p][c][hw] += W[c][:] . U[p][:][hw] + b[c]; planes_fm = fragment-major planes of the [256, K] weight
 hipError_t launch_union_conv_x3t16(hipStream_t s, const float* U, const int64_t* u_off, const void* planes_fm, const float* bias,
-                                   float* V, int P, int K, float* slab) {
+                                   float* V, int P, int K, float* slab, int tile_base) {
   if (K % kBK != 0 || P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16p(planes_fm)) return hipErrorInvalidValue;
   GemmOperand A{U, (int64_t)K * kUHW, nullptr, P, u_off};
   const FmPlanes B{reinterpret_cast<const __bf16*>(planes_fm), K / 32, 16};
-  return launch_x3t16c<AC_UNION, EpiUnionRows>(s, A, B, P * kUHW, 256, K, EpiUnionRows{V, bias, 256}, slab);
+  return launch_x3t16c<AC_UNION, EpiUnionRows>(s, A, B, P * kUHW, 256, K, EpiUnionRows{V, bias, 256}, slab, tile_base);
 }
 
 // Conv2d(128, 256, 3, padding 1) -> ReLU -> BN: planes_fm = planes of the (ky, kx, ci)-ordered [256, 1152] weight, c2 = channel-last
 // [P][7][7][128]
 hipError_t launch_mask_conv2_x3t16(hipStream_t s, const void* planes_fm, const float* c2, const float* bias, const float* scale,
-                                   const float* shift, float* V, int P, float* slab) {
+                                   const float* shift, float* V, int P, float* slab, int tile_base) {
   if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30) || !al16p(planes_fm) || !al16p(c2)) return hipErrorInvalidValue;
   GemmOperand A{c2, 0, nullptr, 0};
   const FmPlanes B{reinterpret_cast<const __bf16*>(planes_fm), 1152 / 32, 16};
-  return launch_x3t16c<AC_CONV2, EpiConvRows>(s, A, B, P * kUHW, 256, 1152, EpiConvRows{V, bias, scale, shift, 256}, slab);
+  return launch_x3t16c<AC_CONV2, EpiConvRows>(s, A, B, P * kUHW, 256, 1152, EpiConvRows{V, bias, scale, shift, 256}, slab, tile_base);
+}
+
+// the second engine's fused pair-conv launch (gemm_bf16x3_t16c.h pair_conv_fused_x3_kernel): the first
+// pair_convs_fused_tiles_x3(P) tiles (128 rows x 128 channels; both channel halves of a row panel are neighbours) of a launch =
+// its whole rounds of two workgroups per CU, when there are at least two; 0 = not fused
+int pair_convs_fused_tiles_x3(int P) {
+  if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return 0;
+  const int tiles = ((P * kUHW + 127) / 128) * 2;
+  const int G = num_cus() * kTiles[TILE_T128x128].blocks_per_cu;
+  const int rounds = tiles / G;
+  return rounds >= 2 ? rounds * G : 0;
+}
+hipError_t launch_pair_convs_fused_x3t16(hipStream_t s, const void* w4_planes_fm, const float* c2, const float* bias4, const float* scale,
+                                         const float* shift, const float* U, const int64_t* u_off, const void* wu_planes_fm,
+                                         const float* bias1, float* V, int P, int K, int ntiles) {
+  using T = Tile16<128, 128>;
+  static DeviceMarks marks;
+  auto kern = pair_conv_fused_x3_kernel<T>;
+  {
+    hipError_t er = marks.raise_lds(reinterpret_cast<const void*>(kern), X3T16<T>::LDS_BYTES);
+    if (er != hipSuccess) return er;
+  }
+  const int G = num_cus() * kTiles[TILE_T128x128].blocks_per_cu;
+  const int M = P * kUHW, tm = (M + T::BM - 1) / T::BM, tiles = tm * 2;
+  if (P <= 0 || K % kBK != 0 || ntiles <= 0 || ntiles % G != 0 || ntiles > tiles || !al16p(w4_planes_fm) || !al16p(wu_planes_fm) || !al16p(c2))
+    return hipErrorInvalidValue;
+  GemmOperand A2{c2, 0, nullptr, 0}, A1{U, (int64_t)K * kUHW, nullptr, P, u_off};
+  const FmPlanes B2{reinterpret_cast<const __bf16*>(w4_planes_fm), 1152 / 32, 16}, B1{reinterpret_cast<const __bf16*>(wu_planes_fm), K / 32, 16};
+  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A2, B2, A1, B1, M, K, tm, tiles, ntiles / G, 2,
+                     EpiConvRows{V, bias4, scale, shift, 256}, EpiUnionRows{V, bias1, 256});
+  return hipGetLastError();
 }
 
 }  // namespace sttran
