@@ -287,7 +287,7 @@ gemm16x3c_kernel(GemmOperand A, FmPlanes B, int M, int N, int K, int tiles_m, in
 //      for stream-K); the leftover tiles go through the two launches above with `tile_base`
 template <class T>
 __global__ void __launch_bounds__(T::NT, 2)
-pair_conv_fused_x3_kernel(GemmOperand A2, FmPlanes B2, GemmOperand A1, FmPlanes B1, int M, int K1, int tiles_m, int tiles, int dp_per_wg,
+pair_conv_fused_x3_kernel(GemmOperand A2, FmPlanes B2, GemmOperand A1, FmPlanes B1, int M, int K1, int tiles_m, int tiles, int ntiles,
                           int half, EpiConvRows e2, EpiUnionRows e1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3c[];
   constexpr int BM = T::BM, BN = T::BN, NB = T::NB;
@@ -296,9 +296,9 @@ pair_conv_fused_x3_kernel(GemmOperand A2, FmPlanes B2, GemmOperand A1, FmPlanes 
   const int fr = lane & 15, fg = lane >> 4;
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);
-  for (int d = 0; d < dp_per_wg; ++d) {
+  for (int tile = blk; tile < ntiles; tile += G) {         // whole tiles only; the last round may be partly filled
     int tile_m, tile_n;
-    tile_origin_rt(d * G + blk, tiles_m, tiles / tiles_m, half, tile_m, tile_n);
+    tile_origin_rt(tile, tiles_m, tiles / tiles_m, half, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     f32x4 acc[2][NB];
 #pragma unroll

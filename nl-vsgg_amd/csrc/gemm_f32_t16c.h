@@ -451,11 +451,12 @@ struct EpiConvT16 {
 // and launch, one fix-up launch.  Here a workgroup runs the conv3x3's 36 K-steps, applies bias / ReLU / BN to the
 // accumulators in registers, runs the union conv's K-steps ON THEM and stores once -- the same arithmetic in the same order
 // (bit-identical to the two launches on tiles neither of them splits).  The ReLU between the two K ranges makes a tile
-// indivisible for stream-K, so this kernel takes only the launch's WHOLE rounds of tiles (dp_per_wg per workgroup); the
-// leftover tiles go through the two single-convolution launches with `tile_base` (their stream-K balances the tail).
+// indivisible for stream-K, so this kernel takes whole tiles only: the launch's whole rounds, plus the leftover tiles
+// when they fill most of another round (pair_convs_fused_tiles); otherwise the leftover goes through the two single-convolution
+// launches with `tile_base` (their stream-K balances the tail).
 template <int ABL = 0>
 __global__ void __launch_bounds__(Tile16C<B_CONV2>::NT, 2)
-pair_conv_fused_kernel(GemmOperand A2, GemmOperand B2, GemmOperand A1, GemmOperand B1, int N, int K1, int dp_per_wg, EpiConvT16 e2,
+pair_conv_fused_kernel(GemmOperand A2, GemmOperand B2, GemmOperand A1, GemmOperand B1, int N, int K1, int ntiles, EpiConvT16 e2,
                        EpiUnionT16 e1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   using T2 = Tile16C<B_CONV2>;
@@ -467,8 +468,8 @@ pair_conv_fused_kernel(GemmOperand A2, GemmOperand B2, GemmOperand A1, GemmOpera
   const int G = gridDim.x;
   const int blk = xcd_remap(blockIdx.x, G);
   const int ch0 = wave * 32 + 4 * fg;
-  for (int d = 0; d < dp_per_wg; ++d) {
-    const int n0 = (d * G + blk) * T2::BN;
+  for (int tile = blk; tile < ntiles; tile += G) {           // whole tiles only; the last round may be partly filled
+    const int n0 = tile * T2::BN;
     f32x4 acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -71,17 +71,20 @@ hipError_t launch_mask_conv2_t16(hipStream_t s, const float* w4, const float* c2
 }
 
 // How many column tiles of a P-pair launch the fused kernel takes: the whole rounds of one workgroup per CU, when there are at
-// least two of them (below that the two single-convolution launches' stream-K fills the chip better); 0 = not fused
+// least two of them (below that the two single-convolution launches' stream-K fills the chip better) -- and the leftover tiles
+// too when they fill most of another round (a round at >= 70 % of the grid costs less than the two stream-K launches + fix-ups
+// over the same tiles: 16x12 x 64 clips leaves 216 of 256, 375 us against 440); 0 = not fused
 int pair_convs_fused_tiles(int P) {
   if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return 0;
   const int tiles = (P * kUHW + 127) / 128;
   const int G = num_cus() * kTiles[TILE_256x128].blocks_per_cu;
-  const int rounds = tiles / G;
-  return rounds >= 2 ? rounds * G : 0;
+  const int rounds = tiles / G, left = tiles - rounds * G;
+  if (rounds < 2) return 0;
+  return left * 10 >= G * 7 ? tiles : rounds * G;
 }
 
 // conv3x3 -> ReLU -> BN, then the union conv on the same accumulators, for the first `ntiles` column tiles (a multiple of the
-// grid: pair_convs_fused_tiles); the caller runs the two launches above with tile_base = ntiles for the rest
+// grid, or all of them: pair_convs_fused_tiles); the caller runs the two launches above with tile_base = ntiles for the rest
 hipError_t launch_pair_convs_fused_t16(hipStream_t s, const float* w4, const float* c2, const float* bias4, const float* scale,
                                        const float* shift, const float* U, const int64_t* u_off, const float* W, const float* bias1,
                                        float* V, int P, int K, int ntiles) {
@@ -93,10 +96,11 @@ hipError_t launch_pair_convs_fused_t16(hipStream_t s, const float* w4, const flo
     if (e != hipSuccess) return e;
   }
   const int G = num_cus() * kTiles[TILE_256x128].blocks_per_cu;
-  if (P <= 0 || K % kBK != 0 || ntiles <= 0 || ntiles % G != 0 || (int64_t)ntiles * 128 > (int64_t)P * kUHW + 127) return hipErrorInvalidValue;
+  const int tiles_all = (P * kUHW + 127) / 128;
+  if (P <= 0 || K % kBK != 0 || ntiles <= 0 || ntiles > tiles_all || (ntiles % G != 0 && ntiles != tiles_all)) return hipErrorInvalidValue;
   GemmOperand A2{w4, 1152, nullptr, 0, nullptr}, B2{c2, 0, nullptr, 0, nullptr};
   GemmOperand A1{W, (int64_t)K, nullptr, 0, nullptr}, B1{U, (int64_t)K * kUHW, nullptr, P, u_off};
-  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), T::LDS_BYTES, s, A2, B2, A1, B1, P * kUHW, K, ntiles / G,
+  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), T::LDS_BYTES, s, A2, B2, A1, B1, P * kUHW, K, ntiles,
                      EpiConvT16{V, bias4, scale, shift, 256}, EpiUnionT16{V, bias1, 256});
   return hipGetLastError();
 }

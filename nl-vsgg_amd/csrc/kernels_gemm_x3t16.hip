@@ -176,8 +176,9 @@ int pair_convs_fused_tiles_x3(int P) {
   if (P <= 0 || (int64_t)P * kUHW >= ((int64_t)1 << 30)) return 0;
   const int tiles = ((P * kUHW + 127) / 128) * 2;
   const int G = num_cus() * kTiles[TILE_T128x128].blocks_per_cu;
-  const int rounds = tiles / G;
-  return rounds >= 2 ? rounds * G : 0;
+  const int rounds = tiles / G, left = tiles - rounds * G;
+  if (rounds < 2) return 0;
+  return left * 10 >= G * 7 ? tiles : rounds * G;      // (the leftover too when it fills most of another round)
 }
 hipError_t launch_pair_convs_fused_x3t16(hipStream_t s, const void* w4_planes_fm, const float* c2, const float* bias4, const float* scale,
                                          const float* shift, const float* U, const int64_t* u_off, const void* wu_planes_fm,
@@ -191,11 +192,11 @@ hipError_t launch_pair_convs_fused_x3t16(hipStream_t s, const void* w4_planes_fm
   }
   const int G = num_cus() * kTiles[TILE_T128x128].blocks_per_cu;
   const int M = P * kUHW, tm = (M + T::BM - 1) / T::BM, tiles = tm * 2;
-  if (P <= 0 || K % kBK != 0 || ntiles <= 0 || ntiles % G != 0 || ntiles > tiles || !al16p(w4_planes_fm) || !al16p(wu_planes_fm) || !al16p(c2))
+  if (P <= 0 || K % kBK != 0 || ntiles <= 0 || ntiles > tiles || (ntiles % G != 0 && ntiles != tiles) || !al16p(w4_planes_fm) || !al16p(wu_planes_fm) || !al16p(c2))
     return hipErrorInvalidValue;
   GemmOperand A2{c2, 0, nullptr, 0}, A1{U, (int64_t)K * kUHW, nullptr, P, u_off};
   const FmPlanes B2{reinterpret_cast<const __bf16*>(w4_planes_fm), 1152 / 32, 16}, B1{reinterpret_cast<const __bf16*>(wu_planes_fm), K / 32, 16};
-  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A2, B2, A1, B1, M, K, tm, tiles, ntiles / G, 2,
+  hipLaunchKernelGGL(kern, dim3(G), dim3(T::NT), X3T16<T>::LDS_BYTES, s, A2, B2, A1, B1, M, K, tm, tiles, ntiles, 2,
                      EpiConvRows{V, bias4, scale, shift, 256}, EpiUnionRows{V, bias1, 256});
   return hipGetLastError();
 }
