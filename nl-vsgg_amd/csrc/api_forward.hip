@@ -512,7 +512,9 @@ int forward_on(SttranHandle* h, const SttranInputs* in_, const SttranOutputs* ou
     const int64_t ncols = (int64_t)P * 49, fcols = std::min<int64_t>(ncols, ft ? (int64_t)ft * 128 : (int64_t)(ft3 / 2) * 128),
                   rcols = ncols - fcols;
     if ((ft | ft3) != 0) {
-      ProfScope ps(h, s, STTRAN_PROF_UNION_CONV, 2.0 * 256 * fcols * (1152 + FD),
+      // (profiling class: GEMM -- the class the line's `roofline` is computed on then holds every GEMM-shaped launch of the
+      //  step, both convolutions included; the union-conv class keeps the union conv's leftover launch, if any)
+      ProfScope ps(h, s, STTRAN_PROF_GEMM, 2.0 * 256 * fcols * (1152 + FD),
                    4.0 * fcols * (FD + 128 + 256) + 4.0 * 256 * (FD + 1152),
                    ft ? "pair_conv_fused_kernel<Tile16C>" : "pair_conv_fused_x3_kernel<Tile16<128,128>>", 256, fcols, 1152 + FD);
       if (ft)

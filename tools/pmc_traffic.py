@@ -17,10 +17,10 @@ import sys
 
 import pandas as pd
 
-# (kernel names carry their parameter types: pair_conv_fused_kernel(..., EpiConvT16, EpiUnionT16) falls under "EpiUnion", and
-#  not under the gemm class, whose pattern asks for the epilogue inside a gemm*_kernel<...> template list)
-CLASSES = [("gemm", r"gemm(_sk|16c?)_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)|gemm(16c?)?_fixup(_vec)?_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)"),
-           ("union_conv", r"EpiUnion"), ("attention", r"attention"), ("layernorm", r"layernorm"),
+# (the fused pair-conv kernels belong to the gemm class, like their ProfScope in api_forward.hip; kernel names carry their
+#  parameter types -- pair_conv_fused_kernel(..., EpiConvT16, EpiUnionT16) -- hence the explicit exclusion under union_conv)
+CLASSES = [("gemm", r"gemm(_sk|16c?)_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)|gemm(16c?)?_fixup(_vec)?_kernel<.*(EpiLinear|EpiHeads|EpiConvRelBn|EpiConvT16)|pair_conv_fused"),
+           ("union_conv", r"^(?!.*pair_conv_fused).*EpiUnion"), ("attention", r"attention"), ("layernorm", r"layernorm"),
            ("mask_conv", r"mask_conv1_pool"), ("index", r"pair_prep|gather_rows|objcls")]
 
 
@@ -41,9 +41,7 @@ def main():
         if not len(f):
             continue
         main_launch = f[~f["Kernel_Name"].str.contains("fixup")]
-        fused = main_launch[main_launch["Kernel_Name"].str.contains("pair_conv_fused_kernel")]
-        # the union-conv class of a step = the fused pair-conv launch + the union conv's launch over the leftover tiles: one unit
-        n = len(fused) if name == "union_conv" and len(fused) else len(main_launch)
+        n = len(main_launch)
         rd = float(f["Counter_Value"].sum()) * 1024 * 2       # gfx950: FETCH_SIZE = 1/2 of streamed bytes
         wr = float(w["Counter_Value"].sum()) * 1024
         out[name] = {"launches": int(n), "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / n,

@@ -48,10 +48,10 @@ done
 # ... and of every kernel class of the step side by side, the non-GEMM kernels included (round 5)
 python3 tools/pmc_kernels.py "$O/${P}_pmc_busy_" "$C" mask_conv1_pool_kernel attention_short_kernel layernorm_kernel pair_conv_fused_kernel \
   "gemm16c_kernel<sttran::Tile16C<4>" "gemm16c_kernel<sttran::Tile16C<2>" "Tile16<128, 176>" "Tile16<128, 128>" > "$O/${P}_pmc_kernels.json"
-# ... and of the second engine's kernels (round 6: gemm16x3_kernel / gemm16x3c_kernel / split_fm_kernel)
+# ... and of the second engine's kernels (round 6: gemm16x3_kernel / pair_conv_fused_x3_kernel / gemm16x3c_kernel / split_fm_kernel)
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU; do pmc busyx3 $c --gemm-engine bf16x3 --steps 3 --warmup 1; done
 python3 tools/pmc_kernels.py "$O/${P}_pmc_busyx3_" "$C" "gemm16x3_kernel<sttran::Tile16<128, 176>" "gemm16x3_kernel<sttran::Tile16<128, 128>" \
-  "gemm16x3c_kernel" "split_fm_kernel" "gemm_x3_kernel" "layernorm_kernel" > "$O/${P}_x3_pmc.json"
+  "pair_conv_fused_x3_kernel" "gemm16x3c_kernel" "split_fm_kernel" "gemm_x3_kernel" "layernorm_kernel" > "$O/${P}_x3_pmc.json"
 # 4. bench lines (unprofiled)
 # (stdout = the one compact line the driver parses; the full object goes to $BENCH_DETAIL)
 BENCH_DETAIL="$O/${P}_bench_default_detail.json" python3 bench.py > "$O/${P}_bench_default_with_cpu.json" 2> "$O/${P}_bench_default.err"
