@@ -207,7 +207,8 @@ def test_bench_default_line_shape():
     rf = c["roofline"]
     assert "gemm16_kernel" in rf["dominant_kernel"] and 0 < rf["dominant_frac"] < 1 and rf["dominant_launches_per_step"] >= 1
     assert not any(isinstance(v, (dict, list)) for v in rf.values())          # flat: what the driver's record keeps
-    assert rf["ms_gemm"] > rf["ms_union_conv"] > rf["ms_mask_conv"] > 0 and rf["ms_attention"] > 0 and rf["ms_layernorm"] > 0
+    # (ms_union_conv: only the union conv's launch over the tiles the fused pair-conv kernel -- GEMM class -- leaves: 0 at this shape)
+    assert rf["ms_gemm"] > rf["ms_mask_conv"] > 0 and rf["ms_union_conv"] >= 0 and rf["ms_attention"] > 0 and rf["ms_layernorm"] > 0
     # the reference's one-clip loop: coalesced on the lanes, lanes only (`one_clip_per_pass.value`, as in rounds 1-4), serial
     o, oc = c["one_clip_per_pass"], c["one_clip_coalesced"]
     assert oc["coalesce"] == 16 and oc["value"] > o["value"] > o["serial"] > 0 and oc["no_hints"] > o["value"]
