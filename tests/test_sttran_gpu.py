@@ -160,6 +160,33 @@ def test_packed_clips_equal_single_clips(predcls):
             np.testing.assert_allclose(many[k].cpu().numpy(), one[k], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("n_clips", [8, 10, 11])
+def test_fused_pair_convs_on_a_by_pointer_batch(n_clips, predcls):
+    """Batches large enough for pair_conv_fused_kernel (conv3x3 -> ReLU -> BN and the union conv in one pass over a tile:
+    launches of two or more rounds of 256-workgroup grids): 8 clips of 16 x 12 = 1 408 pairs = 539 column tiles -> 512 fused
+    + 27 through the two single-convolution launches (tile_base); 10 clips = 674 tiles -> 512 + 162 (under 70 % of a round: the
+    two launches again, with a bigger tail); 11 clips = 742 tiles -> the leftover 230 fills 90 % of a round: all fused, the last
+    round partly filled.  By pointer (per-clip tables: the fused kernel's union operand goes through
+    `rowoff`) and by copy must agree bit for bit, every clip must agree with its single-clip forward (two launches, other
+    stream-K splits) to rounding -- on both engines (the second one fuses its own pair of launches at 1 024 tiles)."""
+    from nl_vsgg_amd.lib.sttran import pack_clips, unpack_predictions
+    clips = [_cuda_entry(syn.make_entry(900 + i, [11] * 16)) for i in range(n_clips)]
+    for eng in ENGINES:
+        predcls.gemm_engine = eng
+        try:
+            by_copy = unpack_predictions(predcls(pack_clips([dict(e) for e in clips])))
+            by_ptr = unpack_predictions(predcls(pack_clips([dict(e) for e in clips], copy=False)))
+            torch.cuda.synchronize()
+            for e, a, b in zip(clips, by_copy, by_ptr):
+                one = predcls(dict(e))
+                for k in OUT_KEYS:
+                    np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg="%s %s" % (eng, k))
+                    np.testing.assert_allclose(b[k].cpu().numpy(), one[k].cpu().numpy(), atol=2e-5 if eng == "fp32" else 1e-4, rtol=0,
+                                               err_msg="%s %s" % (eng, k))
+        finally:
+            predcls.gemm_engine = "fp32"
+
+
 RAGGED_BATCH = [[2, 3, 1], [4], [1, 0, 2, 2], [3, 3], [0, 5, 0, 0, 2], [7, 1]]
 
 
