@@ -82,13 +82,17 @@ int sttran_set_lanes(SttranHandle* h, int32_t lanes) {
 int32_t sttran_num_lanes(SttranHandle* h) { return h ? (int32_t)h->lanes.size() : 0; }
 
 int sttran_lane_stream(SttranHandle* h, int32_t lane, void** stream) {
-  if (!h || !stream || lane < 0 || lane >= (int)h->lanes.size()) return STTRAN_ERR_INVALID;
+  if (!h) return STTRAN_ERR_INVALID;
+  if (!stream || lane < 0 || lane >= (int)h->lanes.size())
+    return fail(h, STTRAN_ERR_INVALID, "lane_stream: lane " + std::to_string(lane) + " of " + std::to_string(h->lanes.size()));
   *stream = h->lanes[lane]->own;
   return STTRAN_OK;
 }
 
 int sttran_lane_join(SttranHandle* h, int32_t lane, void* stream_) {
-  if (!h || lane < -1 || lane >= (int)h->lanes.size()) return STTRAN_ERR_INVALID;
+  if (!h) return STTRAN_ERR_INVALID;
+  if (lane < -1 || lane >= (int)h->lanes.size())
+    return fail(h, STTRAN_ERR_INVALID, "lane_join: lane " + std::to_string(lane) + " of " + std::to_string(h->lanes.size()));
   HIPCK(hipSetDevice(h->cfg.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
   for (int i = 0; i < (int)h->lanes.size(); ++i) {

@@ -25,13 +25,21 @@ def _free_port():
 COMPACT_LIMIT = 6000
 
 
-def _run(cmd, extra_env=None, timeout=420):
+def _run(cmd, extra_env=None, timeout=420, oversubscribed=False):
     """run bench.py; returns (the ONE compact stdout line, the detail object rank 0 wrote to $BENCH_DETAIL)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
     with tempfile.TemporaryDirectory() as tmp:
         env["BENCH_DETAIL"] = os.path.join(tmp, "detail.json")
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0 and oversubscribed and "HSA_STATUS_ERROR_" in r.stderr:
+            # Several ranks TIME-SLICING one GPU (these tests only; the driver runs one rank per GPU): the runtime aborted a
+            # queue in 2 of ~25 eight-rank runs of this command at a larger step (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION; DESIGN
+            # section 6 has the ledger, tools/experiments/oversub_probe.py the probe) and never with one process on the GPU
+            # (a 400-step soak, every other test).  What these tests are for is the record, the gather, the LPT split and the
+            # merged recall under N ranks: one retry on exactly that signature, and the first failure is printed.
+            print("retrying once after a queue abort under GPU time-slicing:\n" + r.stderr[-1500:])
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0
@@ -168,7 +176,8 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
         pytest.skip("no GPU")
     t0 = time.time()
     c, d = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline",
-                 "--no-roofline", "--clips-per-step", "2", "--strong-clips", "16", "--ag-clips", "64"], GLOO_ON_GPU0, timeout=600)
+                 "--no-roofline", "--clips-per-step", "2", "--strong-clips", "16", "--ag-clips", "64"], GLOO_ON_GPU0, timeout=600,
+                oversubscribed=True)
     wall = time.time() - t0
     assert wall < 300, wall
     s64 = _check_ranks_line(c, d, 2, n=8)
