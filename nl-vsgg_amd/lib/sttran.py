@@ -457,6 +457,8 @@ class STTran(torch.nn.Module):
         """Wait for the current stream and raise if a kernel met an out-of-range pair_idx / labels entry since the
         last check (what `check_indices=True` does after every call)."""
         self._flush()
+        if self._handle is None:                        # no forward has run yet: nothing enqueued, nothing to check
+            return
         stream = torch.cuda.current_stream(torch.device("cuda", self._device)).cuda_stream
         rc = self._lib.sttran_sync_check(self._handle, C.c_void_p(stream))
         self._drop_inflight(done=True)                  # sync_check joined every lane and waited for the device

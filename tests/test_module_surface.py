@@ -87,6 +87,7 @@ def test_reference_call_sequences_run_verbatim_without_a_gpu(monkeypatch):
         with pytest.raises(RuntimeError):
             m.to("cpu")
         assert m.to(torch.float32) is m                                    # a dtype-only `.to` changes nothing
+        assert m._handle is None and m.sync_check() is None                # no forward yet: no handle, nothing to wait for
 
 
 @pytest.mark.gpu
